@@ -1,0 +1,649 @@
+"""CPU oracle (numpy, float64) for the per-timestep LIP-MPC / LDCBF step QP.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the shipped package imports this file; only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may.
+
+It restates, in plain numpy, the algorithm of the reference's hot path.  Citations are
+``file:line`` relative to the reference checkout (``HumanoidNavigation/...``):
+
+* LIP dynamics ``x+ = A x + B u``                      MPC/HumanoidMpc.py:34-48, 335-343
+* heading preprocessing (theta / omega)                 MPC/HumanoidMpc.py:137-160
+* closest point / unit normal / inside flip             Utils/ObstaclesUtils.py:50-109
+* LDCBF rows  eta^T (p_k - c) - delta >= 0, k = 0..N    MPC/HumanoidMpc.py:252-294,
+                                                        MPC/HumanoidMPCVariants/HumanoidMPCCustomLCBF.py:30-31
+* leg reachability rows                                 MPC/HumanoidMpc.py:183-202, 232-236
+* manoeuvrability rows                                  MPC/HumanoidMpc.py:204-219, 238-243
+* walking-velocity rows                                 MPC/HumanoidMpc.py:162-181, 245-249
+* cost  sum_{k=0..N} |p_k - goal|^2                     MPC/HumanoidMpc.py:321-333
+* closed-loop driver                                    MPC/HumanoidMpc.py:380-459
+* constants                                             config.yml:2-17, MPC/HumanoidMpc.py:20-22, :200
+
+Parity pinning status
+---------------------
+* geometry (c, eta, inside flag): PINNED bit-for-bit/1e-12 against the reference's own
+  ``ObstaclesUtils`` imported in the build container (fixtures in ``tests/golden``).
+* the QP solve: the reference hands the problem to CasADi/IPOPT (``HumanoidMpc.py:97-100,417``,
+  ``casadi`` unpinned in requirements.txt) which is not installable offline, and the
+  reference has no tests or numeric fixtures -> **parity unpinned** for the solve itself.
+  The restated problem is a strictly convex QP with a unique minimiser, so the oracle is
+  defined as that exact minimiser; it is cross-checked here by two independent methods
+  (a Mehrotra IPM + active-set polish, and Lawson-Hanson NNLS on the least-distance dual)
+  and softly against closed-loop trajectories recovered from the reference's committed
+  result PDFs (``Assets/ReportResults/*/evolutions``; IPOPT tol=1e-5 leaves those 1e-4..1e-3
+  from the optimum, so that check is a regression, not a parity pin).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# constants (config.yml:2-17; HumanoidMpc.py:20-22; ell at HumanoidMpc.py:200)
+# --------------------------------------------------------------------------------------
+
+
+@dataclass
+class Params:
+    N: int = 3
+    dt: float = 0.4                 # DELTA_T
+    g: float = 9.81                 # GRAVITY_CONST
+    h_com: float = 1.0              # COM_HEIGHT
+    alpha: float = 3.6              # ALPHA
+    l_max: tuple = (0.10, 0.10)     # L_MAX_X, L_MAX_Y
+    l_min: tuple = (-0.1, -0.1)     # L_MIN_X, L_MIN_Y
+    v_min: tuple = (-0.1, 0.1)      # V_MIN
+    v_max: tuple = (0.8, 0.4)       # V_MAX
+    omega_max: float = 0.156 * math.pi
+    ell: float = 0.05
+    sampling_time: float = 0.4
+    # solver knobs (build-defined)
+    tol: float = 1e-9
+    max_iter: int = 60
+    k0_tol: float = 1e-5            # tolerated violation of the constant k=0 LDCBF rows
+                                    # (= the reference's IPOPT constr_viol_tol, HumanoidMpc.py:99)
+
+    @property
+    def beta(self):
+        return math.sqrt(self.g / self.h_com)
+
+    @property
+    def ch(self):
+        return math.cosh(self.beta * self.dt)
+
+    @property
+    def sh(self):
+        return math.sinh(self.beta * self.dt)
+
+    @property
+    def kappa(self):
+        return self.beta * self.sh / (self.ch - 1.0)
+
+
+STATUS_SOLVED, STATUS_MAX_ITER, STATUS_INFEASIBLE, STATUS_DEGENERATE, STATUS_UNCERTIFIED = 0, 1, 2, 3, 4
+
+
+def lip_matrices(P: Params):
+    """A_l, B_l of HumanoidMpc.py:34-48 (state (px,vx,py,vy), input = stance foot)."""
+    b, ch, sh = P.beta, P.ch, P.sh
+    Ad = np.array([[ch, sh / b], [sh * b, ch]])
+    Bd = np.array([1.0 - ch, -b * sh])
+    A = np.zeros((4, 4))
+    A[:2, :2] = Ad
+    A[2:, 2:] = Ad
+    B = np.zeros((4, 2))
+    B[:2, 0] = Bd
+    B[2:, 1] = Bd
+    return A, B
+
+
+def precompute_theta_omega(x0, theta0, goal, P: Params):
+    """HumanoidMpc.py:137-160 — the *current* position is used for every k; the multiplier is
+    sampling_time; no angle wrapping."""
+    theta = [float(theta0)]
+    omega = []
+    for _ in range(P.N):
+        target = math.atan2(goal[1] - x0[2], goal[0] - x0[0]) - theta[-1]
+        w = min(max(target, -P.omega_max), P.omega_max)
+        omega.append(w)
+        theta.append(theta[-1] + w * P.sampling_time)
+    return np.array(theta), np.array(omega)
+
+
+# --------------------------------------------------------------------------------------
+# geometry (ObstaclesUtils.py:50-109)
+# --------------------------------------------------------------------------------------
+
+def point_in_ring(x, ring):
+    """Crossing-number inside test on the closed CCW vertex ring; restates what
+    ``matplotlib.path.Path(hull_vertices).contains_point(x)`` (radius 0) decides
+    (ObstaclesUtils.py:50-57): a +X ray from x, edge endpoints classified by ``y >= x_y``,
+    crossing counted when the edge/ray intersection lies at or to the right of x."""
+    tx, ty = float(x[0]), float(x[1])
+    V = len(ring)
+    inside = False
+    x0v, y0v = float(ring[V - 1][0]), float(ring[V - 1][1])
+    f0 = y0v >= ty
+    for i in range(V):
+        x1v, y1v = float(ring[i][0]), float(ring[i][1])
+        f1 = y1v >= ty
+        if f0 != f1:
+            if ((y1v - ty) * (x0v - x1v) >= (x1v - tx) * (y0v - y1v)) == f1:
+                inside = not inside
+        x0v, y0v, f0 = x1v, y1v, f1
+    return inside
+
+
+def closest_point_and_normal(x, ring):
+    """ObstaclesUtils.py:60-109 on the CCW ring ``points[vertices]`` (edge i = ring[i] ->
+    ring[i+1]).  Returns c(2), eta(2), inside flag, degenerate flag.
+
+    t = clip((x-A).(B-A) / |B-A|^2, 0, 1) with |B-A|^2 formed as sqrt-then-square (:81),
+    c = A + t (B-A) (:85), strictly-smaller distance wins (:92), eta = (x-c)/|x-c| (:97-104),
+    negated when x is inside (:106-107)."""
+    V = len(ring)
+    px, py = float(x[0]), float(x[1])
+    best = math.inf
+    cx = cy = math.nan
+    degenerate = False
+    for i in range(V):
+        ax, ay = float(ring[i][0]), float(ring[i][1])
+        bx, by = float(ring[(i + 1) % V][0]), float(ring[(i + 1) % V][1])
+        ex, ey = bx - ax, by - ay
+        nrm = math.sqrt(ex * ex + ey * ey)
+        den = nrm * nrm
+        if den == 0.0:
+            degenerate = True
+            continue
+        t = ((px - ax) * ex + (py - ay) * ey) / den
+        t = max(0.0, min(1.0, t))
+        qx, qy = ax + t * ex, ay + t * ey
+        dx, dy = qx - px, qy - py
+        d = math.sqrt(dx * dx + dy * dy)
+        if d < best:
+            best, cx, cy = d, qx, qy
+    nx, ny = px - cx, py - cy
+    nn = math.sqrt(nx * nx + ny * ny)
+    if not (nn > 0.0):
+        return np.array([cx, cy]), np.array([0.0, 0.0]), False, True
+    nx, ny = nx / nn, ny / nn
+    inside = point_in_ring((px, py), ring)
+    if inside:
+        nx, ny = -nx, -ny
+    return np.array([cx, cy]), np.array([nx, ny]), inside, degenerate
+
+
+def list_c_and_eta(x0, obstacles):
+    """HumanoidMpc.py:296-319: one (c, eta) per obstacle, all at the *current* CoM."""
+    cs, etas, degen = [], [], False
+    for ring in obstacles:
+        c, eta, _, dg = closest_point_and_normal((x0[0], x0[2]), ring)
+        cs.append(c)
+        etas.append(eta)
+        degen = degen or dg
+    if cs:
+        return np.array(cs), np.array(etas), degen
+    return np.zeros((0, 2)), np.zeros((0, 2)), degen
+
+
+# --------------------------------------------------------------------------------------
+# the step QP, two algebraically identical builders
+# --------------------------------------------------------------------------------------
+
+def n_rows(N, n_obs):
+    """canonical inequality count: reach 4N | manoeuvr N | vel 4N | LDCBF (N+1) n_obs."""
+    return 9 * N + (N + 1) * n_obs
+
+
+def build_qp_position_form(x0, theta, omega, goal, s_v, cs, etas, delta, P: Params):
+    """Position form: variables q = (p_1..p_N) in R^{2N}; rows G q <= h in
+    the canonical order reach | manoeuvr | vel | LDCBF(k=0..N).  The k=0 LDCBF rows have a
+    zero G row and h = eta.(p0 - c) - delta (they are constants of the step).
+
+    v_k = -v_{k-1} + kappa (p_k - p_{k-1}) follows from eliminating u_k between the position
+    and velocity rows of x+ = A x + B u (HumanoidMpc.py:34-48)."""
+    N = P.N
+    n = 2 * N
+    kap = P.kappa
+    n_obs = len(cs)
+    p0 = np.array([x0[0], x0[2]])
+    v0 = np.array([x0[1], x0[3]])
+    # affine maps  p_k = Pm[k] q + pc[k],  v_k = Vm[k] q + vc[k]
+    Pm = np.zeros((N + 1, 2, n))
+    pc = np.zeros((N + 1, 2))
+    pc[0] = p0
+    for k in range(1, N + 1):
+        Pm[k, 0, 2 * (k - 1)] = 1.0
+        Pm[k, 1, 2 * (k - 1) + 1] = 1.0
+    Vm = np.zeros((N + 1, 2, n))
+    vc = np.zeros((N + 1, 2))
+    vc[0] = v0
+    for k in range(1, N + 1):
+        Vm[k] = -Vm[k - 1] + kap * (Pm[k] - Pm[k - 1])
+        vc[k] = -vc[k - 1] + kap * (pc[k] - pc[k - 1])
+    rows, rhs = [], []
+    # leg reachability (HumanoidMpc.py:183-202, 232-236): upper (x,y) then lower (x,y)
+    for k in range(N):
+        c_, s_ = math.cos(theta[k]), math.sin(theta[k])
+        R = np.array([[c_, s_], [-s_, c_]])
+        Dm = R @ (Pm[k + 1] - Pm[k])
+        dc = R @ (pc[k + 1] - pc[k]) + np.array([0.0, s_v[k] * P.ell])
+        for a in range(2):
+            rows.append(Dm[a]); rhs.append(P.l_max[a] - dc[a])
+        for a in range(2):
+            rows.append(-Dm[a]); rhs.append(-(P.l_min[a] - dc[a]))
+    # manoeuvrability (HumanoidMpc.py:204-219, 238-243): state k+1, theta_{k+1}, omega_k
+    for k in range(N):
+        c_, s_ = math.cos(theta[k + 1]), math.sin(theta[k + 1])
+        r = np.array([c_, s_])
+        rows.append(r @ Vm[k + 1])
+        rhs.append(P.v_max[0] - (P.alpha / math.pi) * abs(omega[k]) - r @ vc[k + 1])
+    # walking velocities (HumanoidMpc.py:162-181, 245-249): k = 1..N, s_v[k] on the cos*vy term
+    for k in range(1, N + 1):
+        c_, s_ = math.cos(theta[k]), math.sin(theta[k])
+        W = np.array([[c_, s_], [-s_, c_ * s_v[k]]])
+        Wm = W @ Vm[k]
+        wc = W @ vc[k]
+        for a in range(2):
+            rows.append(Wm[a]); rhs.append(P.v_max[a] - wc[a])
+        for a in range(2):
+            rows.append(-Wm[a]); rhs.append(-(P.v_min[a] - wc[a]))
+    # LDCBF (HumanoidMpc.py:252-294; CustomLCBF.py:30-31): k = 0..N, obstacle order
+    for k in range(N + 1):
+        for j in range(n_obs):
+            rows.append(-(etas[j] @ Pm[k]))
+            rhs.append(etas[j] @ (pc[k] - cs[j]) - delta)
+    G = np.array(rows).reshape(-1, n)
+    h = np.array(rhs)
+    g = np.tile(np.asarray(goal, float), N)
+    return G, h, g
+
+
+def build_qp_reference_form(x0, theta, omega, goal, s_v, cs, etas, delta, P: Params):
+    """The same rows written the way the reference writes them — on (X, U) through A_l, B_l
+    (HumanoidMpc.py:221-249, 284-292, 321-333) — then condensed in U by propagating the
+    dynamics.  Returns G_U, h, H_U, f_U, and the affine map p = T u + t0 to positions.  Used
+    only by tests, to prove the position form is the same problem."""
+    N = P.N
+    A, B = lip_matrices(P)
+    nu = 2 * N
+    # X_k = Xm[k] U + xc[k]
+    Xm = np.zeros((N + 1, 4, nu))
+    xc = np.zeros((N + 1, 4))
+    xc[0] = np.asarray(x0[:4], float)
+    for k in range(N):
+        Sel = np.zeros((2, nu)); Sel[0, 2 * k] = 1.0; Sel[1, 2 * k + 1] = 1.0
+        Xm[k + 1] = A @ Xm[k] + B @ Sel
+        xc[k + 1] = A @ xc[k]
+    rows, rhs = [], []
+    for k in range(N):
+        c_, s_ = math.cos(theta[k]), math.sin(theta[k])
+        dpm = np.stack([Xm[k + 1][0] - Xm[k][0], Xm[k + 1][2] - Xm[k][2]])
+        dpc = np.array([xc[k + 1][0] - xc[k][0], xc[k + 1][2] - xc[k][2]])
+        lm = np.stack([c_ * dpm[0] + s_ * dpm[1], -s_ * dpm[0] + c_ * dpm[1]])
+        lc = np.array([c_ * dpc[0] + s_ * dpc[1], -s_ * dpc[0] + c_ * dpc[1] + s_v[k] * P.ell])
+        for a in range(2):
+            rows.append(lm[a]); rhs.append(P.l_max[a] - lc[a])
+        for a in range(2):
+            rows.append(-lm[a]); rhs.append(-(P.l_min[a] - lc[a]))
+    for k in range(N):
+        c_, s_ = math.cos(theta[k + 1]), math.sin(theta[k + 1])
+        rows.append(c_ * Xm[k + 1][1] + s_ * Xm[k + 1][3])
+        rhs.append(P.v_max[0] - (P.alpha / math.pi) * abs(omega[k]) - (c_ * xc[k + 1][1] + s_ * xc[k + 1][3]))
+    for k in range(1, N + 1):
+        c_, s_ = math.cos(theta[k]), math.sin(theta[k])
+        lm = np.stack([c_ * Xm[k][1] + s_ * Xm[k][3], -s_ * Xm[k][1] + c_ * s_v[k] * Xm[k][3]])
+        lc = np.array([c_ * xc[k][1] + s_ * xc[k][3], -s_ * xc[k][1] + c_ * s_v[k] * xc[k][3]])
+        for a in range(2):
+            rows.append(lm[a]); rhs.append(P.v_max[a] - lc[a])
+        for a in range(2):
+            rows.append(-lm[a]); rhs.append(-(P.v_min[a] - lc[a]))
+    for k in range(N + 1):
+        pm = np.stack([Xm[k][0], Xm[k][2]])
+        pcst = np.array([xc[k][0], xc[k][2]])
+        for j in range(len(cs)):
+            rows.append(-(etas[j] @ pm)); rhs.append(etas[j] @ (pcst - cs[j]) - delta)
+    G = np.array(rows).reshape(-1, nu)
+    h = np.array(rhs)
+    T = np.zeros((2 * N, nu)); t0 = np.zeros(2 * N)
+    for k in range(1, N + 1):
+        T[2 * (k - 1)] = Xm[k][0]; T[2 * (k - 1) + 1] = Xm[k][2]
+        t0[2 * (k - 1)] = xc[k][0]; t0[2 * (k - 1) + 1] = xc[k][2]
+    gg = np.tile(np.asarray(goal, float), N)
+    H = 2.0 * T.T @ T
+    f = 2.0 * T.T @ (t0 - gg)
+    return G, h, H, f, T, t0
+
+
+# --------------------------------------------------------------------------------------
+# solvers
+# --------------------------------------------------------------------------------------
+
+@dataclass
+class QPResult:
+    q: np.ndarray
+    z: np.ndarray
+    s: np.ndarray
+    status: int
+    iters: int
+    active: np.ndarray = field(default=None)
+    margin: float = math.inf
+    rounds: int = 0
+
+
+# solver constants shared (by value) with oracle/lipmpc_oracle.c and the HIP kernel
+IPM_S_FLOOR = 0.1      # initial slack floor
+IPM_Z0 = 30.0          # initial multiplier
+IPM_STEP_FRAC = 0.995  # fraction to the boundary
+IPM_Z_DIVERGE = 1e13   # multiplier blow-up => infeasible
+FIN_RHO = 1e10         # penalty of the active-set equality solve
+FIN_EPS = 1e-9         # sign / violation threshold of the certificate
+FIN_ROUNDS = 8         # max add/drop rounds
+FIN_INNER = 6          # max multiplier iterations per equality solve
+FIN_INNER_TOL = 1e-11
+
+
+def solve_qp_ipm(G, h, g, q0, tol=1e-9, max_iter=60):
+    """min |q-g|^2 s.t. G q <= h by Mehrotra predictor-corrector on the normal equations
+    K = 2I + G^T diag(z/s) G (slack form G q + s = h, s,z > 0).  Start: q0 (the caller passes
+    "stand still", p_k = p_0), s = max(h - G q0, 0.1), z = 30.  Stop when max|r_p| <= tol and
+    mu = s.z/m <= tol.  The dual residual is not part of the test: on the normal equations it
+    stalls near cond(K)*eps, and the active-set finish below recomputes q exactly anyway."""
+    m, n = G.shape
+    q = np.array(q0, float).copy()
+    if m == 0:
+        return QPResult(q=g.copy(), z=np.zeros(0), s=np.zeros(0), status=STATUS_SOLVED, iters=0)
+    s = np.maximum(h - G @ q, IPM_S_FLOOR)
+    z = np.full(m, IPM_Z0)
+    status = STATUS_MAX_ITER
+    it = 0
+    for it in range(max_iter + 1):
+        rd = 2.0 * (q - g) + G.T @ z
+        rp = G @ q + s - h
+        mu = float(s @ z) / m
+        if np.max(np.abs(rp)) <= tol and mu <= tol:
+            status = STATUS_SOLVED
+            break
+        if it == max_iter:
+            break
+        if not (np.max(z) < IPM_Z_DIVERGE) or not np.all(np.isfinite(q)):
+            status = STATUS_INFEASIBLE
+            break
+        d = z / s
+        K = 2.0 * np.eye(n) + (G.T * d) @ G
+        try:
+            L = np.linalg.cholesky(K)
+        except np.linalg.LinAlgError:
+            status = STATUS_INFEASIBLE
+            break
+
+        def kkt_solve(rc):
+            # Newton step for  2dq + G^T dz = -rd ; G dq + ds = -rp ; z ds + s dz = -rc
+            w = (z * rp - rc) / s
+            dq = np.linalg.solve(L.T, np.linalg.solve(L, -rd - G.T @ w))
+            ds = -rp - G @ dq
+            dz = -(rc + z * ds) / s
+            return dq, ds, dz
+
+        dq_a, ds_a, dz_a = kkt_solve(s * z)
+        a_aff = min(_max_step(s, ds_a), _max_step(z, dz_a))
+        mu_aff = float((s + a_aff * ds_a) @ (z + a_aff * dz_a)) / m
+        sigma = (mu_aff / mu) ** 3
+        dq, ds, dz = kkt_solve(s * z + ds_a * dz_a - sigma * mu)
+        a = min(1.0, IPM_STEP_FRAC * min(_max_step(s, ds), _max_step(z, dz)))
+        q = q + a * dq
+        s = s + a * ds
+        z = z + a * dz
+    return QPResult(q=q, z=z, s=s, status=status, iters=it)
+
+
+def _max_step(v, dv):
+    neg = dv < 0
+    if not np.any(neg):
+        return 1.0
+    return min(1.0, float(np.min(-v[neg] / dv[neg])))
+
+
+def eqp_multiplier_method(G, h, g, active, q, y_full):
+    """min |q-g|^2 s.t. G_A q = h_A by the method of multipliers in residual-correction form,
+    warm-started at the IPM point: K_A = 2I + rho G_A^T G_A (one Cholesky), then repeat
+      rd = 2(q-g) + G_A^T y ; r = G_A q - h_A ; dq = -K_A^{-1}(rd + rho G_A^T r) ;
+      q += dq ; y += rho (G_A dq + r)
+    until max(|rd|,|r|) <= 1e-11 (at most 6 times).  Dependent active rows are harmless."""
+    n = G.shape[1]
+    GA, hA = G[active], h[active]
+    y = y_full[active].copy()
+    q = q.copy()
+    if GA.shape[0] == 0:
+        return g.copy(), y, 0.0
+    K = 2.0 * np.eye(n) + FIN_RHO * GA.T @ GA
+    L = np.linalg.cholesky(K)
+    res = math.inf
+    for _ in range(FIN_INNER + 1):
+        rd = 2.0 * (q - g) + GA.T @ y
+        r = GA @ q - hA
+        res = max(float(np.max(np.abs(rd))), float(np.max(np.abs(r))))
+        if res <= FIN_INNER_TOL or _ == FIN_INNER:
+            break
+        dq = np.linalg.solve(L.T, np.linalg.solve(L, -rd - FIN_RHO * (GA.T @ r)))
+        q = q + dq
+        y = y + FIN_RHO * (GA @ dq + r)
+    return q, y, res
+
+
+def finish_active_set(G, h, g, res: QPResult):
+    """Turn the interior-point estimate into the exact minimiser with a KKT certificate.
+    Working set A <- {i : z_i > s_i}; solve the equality-constrained problem on A; if some
+    multiplier is < -1e-9 drop the most negative one, else if some row outside A is violated
+    by more than 1e-9 add the most violated one; repeat (<= 8 rounds).  When neither happens
+    (and the equality solve converged to 1e-9) the point satisfies primal feasibility, dual
+    feasibility and complementarity, i.e. it is the unique optimum of the strictly convex QP."""
+    m = G.shape[0]
+    nz = np.any(G != 0.0, axis=1)
+    A = (res.z > res.s) & nz
+    q, yf = res.q, np.where(A, res.z, 0.0)
+    for rnd in range(1, FIN_ROUNDS + 1):
+        q, y, eres = eqp_multiplier_method(G, h, g, A, q, yf)
+        yf = np.zeros(m); yf[A] = y
+        slack = h - G @ q
+        ymin_i = int(np.argmin(np.where(A, yf, math.inf)))
+        smin_i = int(np.argmin(np.where(~A & nz, slack, math.inf)))
+        if A.any() and yf[ymin_i] < -FIN_EPS:
+            A[ymin_i] = False
+            yf[ymin_i] = 0.0
+            continue
+        if (~A & nz).any() and slack[smin_i] < -FIN_EPS:
+            A[smin_i] = True
+            continue
+        if eres <= FIN_EPS and np.all(np.isfinite(q)):
+            return q, yf, slack, A, rnd, True
+        break
+    return q, yf, None, A, FIN_ROUNDS, False
+
+
+def solve_qp_exact(G, h, g, q0, tol=1e-9, max_iter=60):
+    """IPM, then the certified active-set finish.  status 4 = IPM converged but the finish did
+    not certify within its round budget (the IPM point is returned)."""
+    res = solve_qp_ipm(G, h, g, q0, tol=tol, max_iter=max_iter)
+    res.active = np.zeros(G.shape[0], bool)
+    if res.status != STATUS_SOLVED or G.shape[0] == 0:
+        return res
+    nz = np.any(G != 0.0, axis=1)
+    with np.errstate(divide="ignore"):
+        lr = np.abs(np.log(res.z[nz] / res.s[nz]))
+    res.margin = float(np.min(lr)) if lr.size else math.inf
+    q, y, slack, A, rounds, ok = finish_active_set(G, h, g, res)
+    res.rounds = rounds
+    if ok:
+        res.q, res.z, res.s, res.active = q, y, np.maximum(slack, 0.0), A
+    else:
+        res.status = STATUS_UNCERTIFIED
+        res.active = (res.z > res.s) & nz
+    return res
+
+
+def nnls_lawson_hanson(A, b, tol=1e-13, max_outer=None):
+    """min |A x - b| s.t. x >= 0 — Lawson & Hanson (1974), algorithm NNLS, written out here
+    because it must be independent of the IPM (scipy's ``nnls`` returned inconsistent
+    residuals on these matrices).  Passive-set least squares via numpy ``lstsq``."""
+    m, n = A.shape
+    passive = np.zeros(n, bool)
+    x = np.zeros(n)
+    w = A.T @ (b - A @ x)
+    max_outer = max_outer or 5 * n
+    for _ in range(max_outer):
+        cand = np.where(~passive)[0]
+        if cand.size == 0 or np.max(w[cand]) <= tol:
+            break
+        j = cand[np.argmax(w[cand])]
+        passive[j] = True
+        for _inner in range(5 * n):
+            sP = np.linalg.lstsq(A[:, passive], b, rcond=None)[0]
+            s = np.zeros(n); s[passive] = sP
+            if np.min(sP) > 0.0:
+                x = s
+                break
+            bad = passive & (s <= 0.0)
+            alpha = np.min(x[bad] / (x[bad] - s[bad]))
+            x = x + alpha * (s - x)
+            passive &= ~(np.abs(x) <= 1e-15 * max(1.0, np.max(np.abs(x))))
+            passive &= ~((x <= 0.0))
+            x[~passive] = 0.0
+        w = A.T @ (b - A @ x)
+    return x
+
+
+def solve_qp_ldp_nnls(G, h, g):
+    """Independent check: Lawson & Hanson least-distance programming.  With x = q - g the QP is
+    min |x| s.t. (-G) x >= (G g - h); LDP solves it through NNLS on E = [(-G)^T; (Gg-h)^T],
+    f = e_{n+1}: if the residual r = E u - f is non-zero then x = -r[:n] / r[n]."""
+    nz = np.any(G != 0.0, axis=1)
+    Gn, hn = -G[nz], (G @ g - h)[nz]
+    n = G.shape[1]
+    f = np.zeros(n + 1); f[n] = 1.0
+    tau, x = 1.0, None
+    for _ in range(2):  # second pass rescales by |x| so that r[n] = 1/(1+|x/tau|^2) is O(1)
+        E = np.vstack([Gn.T, hn[None, :] / tau])
+        u = nnls_lawson_hanson(E, f)
+        r = E @ u - f
+        if abs(r[n]) < 1e-13:
+            return None  # infeasible
+        x = -r[:n] / r[n] * tau
+        tau = max(1.0, float(np.linalg.norm(x)))
+    return g + x
+
+
+# --------------------------------------------------------------------------------------
+# one MPC step and the closed loop
+# --------------------------------------------------------------------------------------
+
+def foot_window(step_number, N, start_with_right_foot=True):
+    """HumanoidMpc.py:104-108, 399-403."""
+    base = 0 if start_with_right_foot else 1
+    return [1 if (i % 2) == base else -1 for i in range(step_number, step_number + N + 1)]
+
+
+def recover_trajectory(q, x0, P: Params):
+    """X*(N+1,4), U*(N,2) from positions (Appendix B item 6)."""
+    N = P.N
+    ch, sh, b, kap = P.ch, P.sh, P.beta, P.kappa
+    p = np.vstack([[x0[0], x0[2]], q.reshape(N, 2)])
+    v = np.zeros((N + 1, 2)); v[0] = [x0[1], x0[3]]
+    U = np.zeros((N, 2))
+    for k in range(N):
+        v[k + 1] = -v[k] + kap * (p[k + 1] - p[k])
+        U[k] = (p[k + 1] - ch * p[k] - (sh / b) * v[k]) / (1.0 - ch)
+    X = np.stack([p[:, 0], v[:, 0], p[:, 1], v[:, 1]], axis=1)
+    return X, U
+
+
+def plan_step(state, goal, first_foot, obstacles, delta, P: Params, exact=True):
+    """One MPC step.  state = (px,vx,py,vy,theta); first_foot = s_0 in {+1,-1};
+    obstacles = list of CCW rings (V_j,2).  Returns a dict mirroring the C ABI outputs."""
+    N = P.N
+    x0 = np.asarray(state[:4], float)
+    theta, omega = precompute_theta_omega(x0, state[4], goal, P)
+    s_v = [first_foot if (i % 2 == 0) else -first_foot for i in range(N + 1)]
+    cs, etas, degen = list_c_and_eta(x0, obstacles)
+    n_obs = len(obstacles)
+    m_tot = n_rows(N, n_obs)
+    out = dict(theta=theta, omega=omega, c=cs, eta=etas, status=STATUS_SOLVED, iters=0,
+               U=np.full((N, 2), np.nan), X=np.full((N + 1, 4), np.nan), obj=math.nan,
+               active=np.zeros(m_tot, bool), margin=math.inf)
+    if degen or not np.all(np.isfinite(etas)):
+        out["status"] = STATUS_DEGENERATE
+        return out
+    G, h, g = build_qp_position_form(x0, theta, omega, goal, s_v, cs, etas, delta, P)
+    # k = 0 LDCBF rows are constants of the step (zero G row): they can only make it
+    # infeasible, and are kept out of the solve; their canonical indices are never "active".
+    k0 = slice(9 * N, 9 * N + n_obs)
+    if n_obs and np.any(h[k0] < -P.k0_tol):
+        out["status"] = STATUS_INFEASIBLE
+        return out
+    keep = np.ones(m_tot, bool)
+    keep[k0] = False
+    Gs, hs = G[keep], h[keep]
+    q0 = np.tile([x0[0], x0[2]], N)
+    res = solve_qp_exact(Gs, hs, g, q0, tol=P.tol, max_iter=P.max_iter) if exact else \
+        solve_qp_ipm(Gs, hs, g, q0, tol=P.tol, max_iter=P.max_iter)
+    out["status"], out["iters"], out["rounds"] = res.status, res.iters, res.rounds
+    if res.status not in (STATUS_SOLVED, STATUS_UNCERTIFIED):
+        return out
+    X, U = recover_trajectory(res.q, x0, P)
+    out["X"], out["U"] = X, U
+    p = X[:, [0, 2]]
+    out["obj"] = float(np.sum((p - np.asarray(goal, float)) ** 2))
+    if res.active is not None:
+        out["active"][keep] = res.active
+    out["margin"] = res.margin
+    out["q"] = res.q
+    return out
+
+
+def run_closed_loop(goal, obstacles, N_horizon=3, N_mpc_timesteps=100, sampling_time=0.4,
+                    init_state=(0, 0, 0, 0, 0), start_with_right_foot=True, delta=0.0,
+                    params: Params | None = None, exact=False):
+    """HumanoidMpc.py:345-459 (``run_simulation`` without plotting): returns X_pred (5,K+1),
+    U_pred (3,K) with the reference's truncation rule ``X[:, :k+1], U[:, :k]`` (:457-459).
+
+    ``exact=False`` advances with the interior-point iterate (strictly inside every half-space,
+    like the reference's IPOPT iterate); the exact vertex solution puts the CoM *on* LDCBF
+    boundaries, where the next step's eta = (x-c)/|x-c| (ObstaclesUtils.py:104) is 0/0."""
+    P = params or Params()
+    P.N = N_horizon
+    P.sampling_time = sampling_time
+    mpc_step = int(P.dt / sampling_time) or 1
+    num_inputs = mpc_step * N_mpc_timesteps
+    X_pred = np.zeros((5, num_inputs + 1))
+    U_pred = np.zeros((3, num_inputs))
+    X_pred[:, 0] = np.asarray(init_state, float)
+    last_obj = math.inf
+    u_keep = np.zeros(2)
+    k = 0
+    for k in range(num_inputs):
+        is_mpc = (k % mpc_step) == 0
+        if last_obj < 0.05:
+            break
+        st = X_pred[:, k]
+        step_number = k // mpc_step
+        s0 = foot_window(step_number, 0, start_with_right_foot)[0]
+        if is_mpc:
+            r = plan_step(st, goal, s0, obstacles, delta, P, exact=exact)
+            if r["status"] not in (STATUS_SOLVED, STATUS_UNCERTIFIED):
+                break
+            last_obj = r["obj"]
+            u_keep = r["U"][0]
+            theta1, omega0 = r["theta"][1], r["omega"][0]
+        else:
+            th, om = precompute_theta_omega(st[:4], st[4], goal, P)
+            theta1, omega0 = th[1], om[0]
+        U_pred[:2, k] = u_keep
+        U_pred[2, k] = omega0
+        if is_mpc:
+            A, B = lip_matrices(P)
+            X_pred[:4, k + 1] = A @ st[:4] + B @ u_keep
+        else:
+            X_pred[:4, k + 1] = st[:4]
+        X_pred[4, k + 1] = theta1
+    return X_pred[:, :k + 1], U_pred[:, :k]
