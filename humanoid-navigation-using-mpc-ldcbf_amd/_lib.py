@@ -1,0 +1,66 @@
+"""ctypes binding of liblipmpc.so (C ABI: include/lipmpc.h).  There is no CPU fallback: if the
+HIP library is missing this module raises at import of the solver."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblipmpc.so")
+
+
+class LipmpcParamsC(C.Structure):
+    """struct lipmpc_params (include/lipmpc.h)"""
+    _fields_ = [
+        ("N", C.c_int32), ("n_obs_max", C.c_int32), ("v_max", C.c_int32), ("max_iter", C.c_int32),
+        ("flags", C.c_int32), ("reserved", C.c_int32),
+        ("dt", C.c_double), ("g", C.c_double), ("h_com", C.c_double), ("alpha", C.c_double),
+        ("l_max", C.c_double * 2), ("l_min", C.c_double * 2), ("v_min", C.c_double * 2),
+        ("v_max_xy", C.c_double * 2),
+        ("omega_max", C.c_double), ("ell", C.c_double), ("sampling_time", C.c_double),
+        ("tol", C.c_double), ("k0_tol", C.c_double),
+    ]
+
+
+EXPORTS = ("lipmpc_default_params", "lipmpc_create", "lipmpc_destroy", "lipmpc_num_rows",
+           "lipmpc_active_words", "lipmpc_plan_step_batch", "lipmpc_advance_batch",
+           "lipmpc_strerror", "lipmpc_version")
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C <package>/csrc)")
+    lib = C.CDLL(LIB_PATH)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+    lib.lipmpc_default_params.argtypes = [C.POINTER(LipmpcParamsC)]
+    lib.lipmpc_default_params.restype = i32
+    lib.lipmpc_create.argtypes = [C.POINTER(LipmpcParamsC), i32, C.POINTER(vp)]
+    lib.lipmpc_create.restype = i32
+    lib.lipmpc_destroy.argtypes = [vp]
+    lib.lipmpc_destroy.restype = None
+    lib.lipmpc_num_rows.argtypes = [C.POINTER(LipmpcParamsC)]
+    lib.lipmpc_num_rows.restype = i64
+    lib.lipmpc_active_words.argtypes = [C.POINTER(LipmpcParamsC)]
+    lib.lipmpc_active_words.restype = i64
+    lib.lipmpc_plan_step_batch.argtypes = [vp, i64] + [vp] * 16
+    lib.lipmpc_plan_step_batch.restype = i32
+    lib.lipmpc_advance_batch.argtypes = [vp, i64] + [vp] * 6
+    lib.lipmpc_advance_batch.restype = i32
+    lib.lipmpc_strerror.argtypes = [i32]
+    lib.lipmpc_strerror.restype = C.c_char_p
+    lib.lipmpc_version.argtypes = []
+    lib.lipmpc_version.restype = i32
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().lipmpc_strerror(code).decode()
+        raise RuntimeError(f"{what} failed: {msg} ({code})")

@@ -1,0 +1,156 @@
+"""Drop-in mirrors of the reference's controller classes, running every MPC step on the GPU.
+
+``HumanoidMPC`` keeps the constructor and ``run_simulation`` signature, defaults, return shapes
+and truncation behaviour of HumanoidNavigation/MPC/HumanoidMpc.py:50-52, 345-347, 457-459, 494;
+``HumanoidMPCCustomLCBF`` adds ``distance_from_obstacles`` (HumanoidMPCCustomLCBF.py:15-28).
+Plotting/animation (HumanoidAnimationUtils) is out of scope: the plotting arguments are accepted
+and ignored, and the third return value is ``initial_animator`` (None by default).
+"""
+from __future__ import annotations
+
+import math
+from typing import Union
+
+import numpy as np
+import torch
+
+from .solver import (BatchedLipMpc, LipMpcParams, FLAG_INTERIOR, STATUS_SOLVED, STATUS_UNCERTIFIED, pack_rings)
+
+DELTA_T = 0.4  # config.yml:2
+
+
+def _ring_of(obstacle):
+    """ConvexHull -> CCW vertex ring ``points[vertices]`` (ObstaclesUtils.py:55); arrays pass through."""
+    if hasattr(obstacle, "vertices") and hasattr(obstacle, "points"):
+        return np.asarray(obstacle.points, float)[obstacle.vertices]
+    return np.asarray(obstacle, float)
+
+
+class HumanoidMPC:
+    def __init__(self, goal, obstacles, N_horizon=3, N_mpc_timesteps=100, sampling_time=1e-3,
+                 init_state: Union[np.ndarray, tuple] = np.array([0, 0, 0, 0, 0]),
+                 start_with_right_foot: bool = True, verbosity: int = 1, *, exact: bool = False,
+                 device: int | None = None):
+        # HumanoidMpc.py:66
+        assert DELTA_T % sampling_time <= 1e-8, \
+            "The sampling time must be lower than and divisible by the duration of the step."
+        self.N_horizon = N_horizon
+        self.N_simul = N_mpc_timesteps
+        self.sampling_time = sampling_time
+        self.mpc_step = int(DELTA_T / sampling_time) or 1          # :74-75
+        self.num_inputs = self.mpc_step * self.N_simul              # :78
+        self.start_with_right_foot = start_with_right_foot
+        self.verbosity = verbosity
+        self.goal = goal
+        self.obstacles = obstacles
+        assert self.goal is not None and self.obstacles is not None  # :91
+        if isinstance(init_state, tuple):
+            init_state = np.array(init_state)
+        init_state = np.asarray(init_state, float)
+        assert init_state.shape[0] == 5, "The initial state must be a vector with 5 components."
+        self.init_state = init_state
+        # s_v, HumanoidMpc.py:104-108
+        base = 0 if start_with_right_foot else 1
+        self.s_v = [1 if i % 2 == base else -1 for i in range(self.num_inputs + N_horizon + 1)]
+        self.precomputed_theta = None
+        self.precomputed_omega = None
+        self.distance_from_obstacles = getattr(self, "distance_from_obstacles", 0.0)
+        self._exact = exact
+        self._device = device
+        self._solver = None
+        self._rings = None
+        self.last_status = None
+
+    # -- hooks kept from the reference ------------------------------------------------------------
+    def _get_obstacle_rings(self, x_k: float, y_k: float):
+        """Obstacles seen at this step as CCW rings (override for sensed environments)."""
+        if self._rings is None:
+            self._rings = [_ring_of(o) for o in self.obstacles]
+        return self._rings
+
+    def _make_solver(self, n_obs, v_max):
+        p = LipMpcParams(N=self.N_horizon, n_obs_max=n_obs, v_max=max(3, v_max),
+                         sampling_time=self.sampling_time, flags=0 if self._exact else FLAG_INTERIOR)
+        return BatchedLipMpc(p, self._device)
+
+    def _plan(self, state5, s0):
+        rings = self._get_obstacle_rings(state5[0], state5[2])
+        n_obs = len(rings)
+        v_max = max([3] + [len(r) for r in rings])
+        if self._solver is None or self._solver.params.n_obs_max != n_obs or self._solver.params.v_max < v_max:
+            self._solver = self._make_solver(n_obs, v_max)
+        sv = self._solver
+        dev = sv.device
+        xy, nv = pack_rings([rings], n_obs, sv.params.v_max)
+        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+        out = sv.plan_step_batch(
+            t(state5[None, :], torch.float64), t(np.asarray(self.goal, float)[None, :], torch.float64),
+            t(np.array([s0], np.int8), torch.int8),
+            t(xy, torch.float64) if n_obs else None, t(nv, torch.int32) if n_obs else None,
+            t(np.array([self.distance_from_obstacles], float), torch.float64), with_c_eta=n_obs > 0)
+        torch.cuda.synchronize(dev)
+        return {k: v[0].cpu().numpy() for k, v in out.items()}
+
+    def _get_list_c_and_eta(self, x_k: float, y_k: float):
+        """HumanoidMpc.py:296-319 — (list_c, list_eta) of (2,1) arrays at the given CoM position."""
+        st = np.array([x_k, 0.0, y_k, 0.0, 0.0])
+        r = self._plan(st, 1)
+        if "c_eta" not in r:
+            return [], []
+        return ([ce[:2].reshape(2, 1) for ce in r["c_eta"]], [ce[2:].reshape(2, 1) for ce in r["c_eta"]])
+
+    # -- the closed loop (HumanoidMpc.py:345-494) ------------------------------------------------
+    def run_simulation(self, path_to_gif: str = None, make_fast_plot: bool = True, plot_animation: bool = False,
+                       fill_animator: bool = True, initial_animator=None):
+        X_pred = np.zeros((5, self.num_inputs + 1))
+        U_pred = np.zeros((3, self.num_inputs))
+        X_pred[:, 0] = self.init_state
+        last_obj = float("inf")
+        u_keep = np.zeros(2)
+        ch, sh, beta = self._lip()
+        k = 0
+        for k in range(self.num_inputs):
+            is_mpc = k % self.mpc_step == 0
+            if last_obj < 0.05:                                         # :392-393
+                break
+            st = X_pred[:, k].copy()
+            step_number = math.floor(k / self.mpc_step)
+            r = self._plan(st, self.s_v[step_number])
+            self.precomputed_theta, self.precomputed_omega = r["theta"], r["omega"]
+            if is_mpc:
+                self.last_status = int(r["status"])
+                if self.last_status not in (STATUS_SOLVED, STATUS_UNCERTIFIED):
+                    if self.verbosity > 0:
+                        print(f"===== ERROR ({k}) ===== solver status {self.last_status}")  # :419-429
+                    break
+                last_obj = float(r["obj"])
+                u_keep = r["U"][0]
+            U_pred[:2, k] = u_keep                                      # :432-433
+            U_pred[2, k] = r["omega"][0]
+            if is_mpc:                                                  # :439-447
+                x = st[:4]
+                X_pred[0, k + 1] = ch * x[0] + sh / beta * x[1] + (1 - ch) * u_keep[0]
+                X_pred[1, k + 1] = beta * sh * x[0] + ch * x[1] - beta * sh * u_keep[0]
+                X_pred[2, k + 1] = ch * x[2] + sh / beta * x[3] + (1 - ch) * u_keep[1]
+                X_pred[3, k + 1] = beta * sh * x[2] + ch * x[3] - beta * sh * u_keep[1]
+            else:
+                X_pred[:4, k + 1] = st[:4]
+            X_pred[4, k + 1] = r["theta"][1]
+        return X_pred[:, :k + 1], U_pred[:, :k], initial_animator      # :457-459, 494
+
+    @staticmethod
+    def _lip():
+        beta = math.sqrt(9.81 / 1.0)
+        return math.cosh(beta * DELTA_T), math.sinh(beta * DELTA_T), beta
+
+
+class HumanoidMPCCustomLCBF(HumanoidMPC):
+    """LDCBF with a safety margin: h = eta^T (x - c) - delta (HumanoidMPCCustomLCBF.py:30-31)."""
+
+    def __init__(self, goal, obstacles, N_horizon=3, N_mpc_timesteps=100, sampling_time=1e-3,
+                 init_state=None, start_with_right_foot: bool = True, verbosity: int = 1,
+                 distance_from_obstacles: float = 0.0, **kw):
+        assert distance_from_obstacles >= 0.0, "distance_from_obstacles must be non-negative"
+        self.distance_from_obstacles = distance_from_obstacles
+        super().__init__(goal, obstacles, N_horizon, N_mpc_timesteps, sampling_time,
+                         np.zeros(5) if init_state is None else init_state, start_with_right_foot, verbosity, **kw)

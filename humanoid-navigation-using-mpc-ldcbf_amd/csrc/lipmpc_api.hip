@@ -1,0 +1,146 @@
+// lipmpc_api.hip — C ABI (include/lipmpc.h): handle, parameter checks, kernel dispatch, state advance.
+#include "lipmpc_kernel.hpp"
+
+using namespace lipmpc_dev;
+
+namespace {
+// state advance (HumanoidMpc.py:432-447)
+__global__ void advance_kernel(long B, double ch, double sh_over_beta, double beta_sh, double* __restrict__ state,
+                               int8_t* __restrict__ foot, const double* __restrict__ U, const double* __restrict__ theta,
+                               const int32_t* __restrict__ status, int N) {
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int st = status[b];
+  if (st != LIPMPC_STATUS_SOLVED && st != LIPMPC_STATUS_UNCERTIFIED) return;
+  double* x = state + b * 5;
+  const double ux = U[b * N * 2 + 0], uy = U[b * N * 2 + 1];
+  const double px = x[0], vx = x[1], py = x[2], vy = x[3];
+  // A_l x + B_l u  (HumanoidMpc.py:34-48)
+  x[0] = ch * px + sh_over_beta * vx + (1.0 - ch) * ux;
+  x[1] = beta_sh * px + ch * vx - beta_sh * ux;
+  x[2] = ch * py + sh_over_beta * vy + (1.0 - ch) * uy;
+  x[3] = beta_sh * py + ch * vy - beta_sh * uy;
+  x[4] = theta[b * (N + 1) + 1];
+  foot[b] = (int8_t)(-foot[b]);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+struct lipmpc_handle {
+  lipmpc_params p;
+  KArgs k;
+  int device;
+  int G;
+  int nobs_l;
+};
+
+extern "C" {
+
+int lipmpc_default_params(lipmpc_params* p) {
+  if (!p) return LIPMPC_E_ARG;
+  memset(p, 0, sizeof(*p));
+  p->N = 3; p->n_obs_max = 0; p->v_max = 5; p->max_iter = 60; p->flags = 0;
+  p->dt = 0.4; p->g = 9.81; p->h_com = 1.0; p->alpha = 3.6;
+  p->l_max[0] = 0.10; p->l_max[1] = 0.10; p->l_min[0] = -0.1; p->l_min[1] = -0.1;
+  p->v_min[0] = -0.1; p->v_min[1] = 0.1; p->v_max_xy[0] = 0.8; p->v_max_xy[1] = 0.4;
+  p->omega_max = 0.156 * M_PI; p->ell = 0.05; p->sampling_time = 0.4;
+  p->tol = 1e-9; p->k0_tol = 1e-5;
+  return LIPMPC_OK;
+}
+
+int64_t lipmpc_num_rows(const lipmpc_params* p) { return p ? 9L * p->N + (long)(p->N + 1) * p->n_obs_max : LIPMPC_E_ARG; }
+int64_t lipmpc_active_words(const lipmpc_params* p) { return p ? (lipmpc_num_rows(p) + 63) / 64 : LIPMPC_E_ARG; }
+
+int lipmpc_create(const lipmpc_params* p, int device, lipmpc_handle** out) {
+  if (!p || !out) return LIPMPC_E_ARG;
+  if (p->N < 1 || p->N > 16 || p->n_obs_max < 0 || p->n_obs_max > 50 || p->v_max < 3 || p->v_max > 32 ||
+      p->max_iter < 1 || !(p->tol > 0.0) || !(p->dt > 0.0) || !(p->h_com > 0.0) || !(p->g > 0.0))
+    return LIPMPC_E_UNSUPPORTED;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return LIPMPC_E_HIP;
+  lipmpc_handle* h = (lipmpc_handle*)calloc(1, sizeof(lipmpc_handle));
+  if (!h) return LIPMPC_E_NOMEM;
+  h->p = *p;
+  h->device = device;
+  h->G = (p->N <= 8) ? 16 : 32;
+  const int need = (p->n_obs_max + 1) / 2;
+  h->nobs_l = need == 0 ? 0 : need <= 2 ? 2 : need <= 5 ? 5 : need <= 13 ? 13 : 25;
+  KArgs& k = h->k;
+  k.N = p->N; k.n_obs = p->n_obs_max; k.nvert_max = p->v_max; k.max_iter = p->max_iter; k.flags = p->flags;
+  k.m_tot = (int)lipmpc_num_rows(p); k.words = (int)lipmpc_active_words(p);
+  const double beta = sqrt(p->g / p->h_com), ch = cosh(beta * p->dt), sh = sinh(beta * p->dt);
+  k.kappa = beta * sh / (ch - 1.0); k.ch = ch; k.sh_over_beta = sh / beta; k.inv_one_minus_ch = 1.0 / (1.0 - ch);
+  k.beta_sh = beta * sh;
+  for (int i = 0; i < 2; ++i) { k.l_max[i] = p->l_max[i]; k.l_min[i] = p->l_min[i]; k.v_min[i] = p->v_min[i]; k.v_max[i] = p->v_max_xy[i]; }
+  k.alpha_over_pi = p->alpha / M_PI; k.omega_max = p->omega_max; k.ell = p->ell; k.tau = p->sampling_time;
+  k.tol = p->tol; k.k0_tol = p->k0_tol;
+  *out = h;
+  return LIPMPC_OK;
+}
+
+void lipmpc_destroy(lipmpc_handle* h) { free(h); }
+
+#define LAUNCH(GG, NL)                                                                                         \
+  launch_plan_step<GG, NL>(h->k, (long)B, state, goal, first_foot, delta, obs_xy, obs_nv, U, X, theta, omega, obj, \
+                           status, iters, (unsigned long long*)active, c_eta, stream)
+
+int lipmpc_plan_step_batch(lipmpc_handle* h, int64_t B, const double* state, const double* goal,
+                           const int8_t* first_foot, const double* delta, const double* obs_xy,
+                           const int32_t* obs_nv, double* U, double* X, double* theta, double* omega,
+                           double* obj, int32_t* status, int32_t* iters, uint64_t* active, double* c_eta,
+                           void* hip_stream) {
+  if (!h || B < 0) return LIPMPC_E_ARG;
+  if (B == 0) return LIPMPC_OK;
+  if (!state || !goal || !first_foot || !U || !X || !theta || !omega || !obj || !status || !iters || !active)
+    return LIPMPC_E_ARG;
+  if (h->p.n_obs_max > 0 && (!obs_xy || !obs_nv)) return LIPMPC_E_ARG;
+  if (hipSetDevice(h->device) != hipSuccess) return LIPMPC_E_HIP;
+  hipStream_t stream = (hipStream_t)hip_stream;
+  if (h->G == 16) {
+    switch (h->nobs_l) {
+      case 0: LAUNCH(16, 0); break;
+      case 2: LAUNCH(16, 2); break;
+      case 5: LAUNCH(16, 5); break;
+      case 13: LAUNCH(16, 13); break;
+      default: LAUNCH(16, 25); break;
+    }
+  } else {
+    switch (h->nobs_l) {
+      case 0: LAUNCH(32, 0); break;
+      case 2: LAUNCH(32, 2); break;
+      case 5: LAUNCH(32, 5); break;
+      case 13: LAUNCH(32, 13); break;
+      default: LAUNCH(32, 25); break;
+    }
+  }
+  return hipGetLastError() == hipSuccess ? LIPMPC_OK : LIPMPC_E_HIP;
+}
+
+int lipmpc_advance_batch(lipmpc_handle* h, int64_t B, double* state, int8_t* first_foot, const double* U,
+                         const double* theta, const int32_t* status, void* hip_stream) {
+  if (!h || B < 0) return LIPMPC_E_ARG;
+  if (B == 0) return LIPMPC_OK;
+  if (!state || !first_foot || !U || !theta || !status) return LIPMPC_E_ARG;
+  if (hipSetDevice(h->device) != hipSuccess) return LIPMPC_E_HIP;
+  hipLaunchKernelGGL(advance_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
+                     (long)B, h->k.ch, h->k.sh_over_beta, h->k.beta_sh, state, first_foot, U, theta, status, h->k.N);
+  return hipGetLastError() == hipSuccess ? LIPMPC_OK : LIPMPC_E_HIP;
+}
+
+const char* lipmpc_strerror(int code) {
+  switch (code) {
+    case LIPMPC_OK: return "ok";
+    case LIPMPC_E_ARG: return "invalid argument (null pointer or negative size)";
+    case LIPMPC_E_UNSUPPORTED: return "unsupported parameters (N 1..16, n_obs_max 0..50, v_max 3..32)";
+    case LIPMPC_E_HIP: return "HIP runtime error (no device, bad device index or launch failure)";
+    case LIPMPC_E_NOMEM: return "out of host memory";
+    default: return "unknown error";
+  }
+}
+
+int lipmpc_version(void) { return LIPMPC_ABI_VERSION; }
+
+}  // extern "C"

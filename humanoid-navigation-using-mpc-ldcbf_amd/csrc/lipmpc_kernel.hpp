@@ -1,0 +1,683 @@
+// lipmpc_kernel.hpp — batched LIP-MPC / LDCBF step solver for gfx950 (MI355X), C ABI in include/lipmpc.h.
+//
+// One QP per group of G lanes (G = 16 for N <= 8, 32 for N <= 16; 4 or 2 problems per
+// 64-wide wavefront).  Lane l of a group owns decision variable l = 2a + c, i.e. coordinate c
+// of the CoM position p_{a+1} (position form of the QP: H = 2I), and the
+// inequality rows of "its" stage:
+//   c = 0: leg-reach x (upper, lower), walking-velocity longitudinal (upper, lower), manoeuvrability
+//   c = 1: leg-reach y (upper, lower), walking-velocity lateral (upper, lower)
+//   LDCBF rows of stage a+1: obstacle j on lane c = j & 1.
+// Rows are generated, never stored: G q, G^T w and K = 2I + G^T D G are applied through the
+// problem's structure (rotation blocks, the alternating-sum velocity map, per-stage 2x2 LDCBF
+// blocks), so a problem's live state is n + ~2.5 m doubles in registers.
+//
+// Reference semantics followed (HumanoidNavigation/...):
+//   theta/omega            MPC/HumanoidMpc.py:137-160
+//   closest point / eta    Utils/ObstaclesUtils.py:50-109
+//   rows                   MPC/HumanoidMpc.py:183-249, 252-294; HumanoidMPCCustomLCBF.py:30-31
+//   cost                   MPC/HumanoidMpc.py:321-333
+//   dynamics / advance     MPC/HumanoidMpc.py:34-48, 335-343, 432-447
+// Solver: Mehrotra predictor-corrector on the normal equations + certified active-set finish
+// (the algorithm of oracle/lipmpc_oracle.py, which is the parity checker, not a dependency).
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/lipmpc.h"
+#pragma once
+
+namespace lipmpc_dev {
+
+// solver constants (same values as the oracle)
+constexpr double IPM_S_FLOOR = 0.1;
+constexpr double IPM_Z0 = 30.0;
+constexpr double IPM_STEP_FRAC = 0.995;
+constexpr double IPM_Z_DIVERGE = 1e13;
+constexpr double FIN_RHO = 1e10;
+constexpr double FIN_EPS = 1e-9;
+constexpr int FIN_ROUNDS = 8;
+constexpr int FIN_INNER = 6;
+constexpr double FIN_INNER_TOL = 1e-11;
+
+struct KArgs {
+  int N, n_obs, nvert_max, max_iter, flags;
+  int m_tot, words;
+  double kappa, ch, sh_over_beta, inv_one_minus_ch, beta_sh;
+  double l_max[2], l_min[2], v_min[2], v_max[2];
+  double alpha_over_pi, omega_max, ell, tau, tol, k0_tol;
+};
+
+// ------------------------------------------------------------------------------------------
+// group-level communication (G lanes, G in {16, 32}); v1 uses the LDS crossbar (ds_bpermute)
+// ------------------------------------------------------------------------------------------
+template <int G> __device__ __forceinline__ double gshfl(double x, int src) { return __shfl(x, src, G); }
+template <int G> __device__ __forceinline__ double gxor(double x, int m) { return __shfl_xor(x, m, G); }
+template <int G> __device__ __forceinline__ double gup(double x, int d) { return __shfl_up(x, d, G); }
+template <int G> __device__ __forceinline__ double gdown(double x, int d) { return __shfl_down(x, d, G); }
+
+template <int G> __device__ __forceinline__ double gsum(double x) {
+#pragma unroll
+  for (int m = 1; m < G; m <<= 1) x += gxor<G>(x, m);
+  return x;
+}
+template <int G> __device__ __forceinline__ double gmin(double x) {
+#pragma unroll
+  for (int m = 1; m < G; m <<= 1) x = fmin(x, gxor<G>(x, m));
+  return x;
+}
+template <int G> __device__ __forceinline__ double gmax(double x) {
+#pragma unroll
+  for (int m = 1; m < G; m <<= 1) x = fmax(x, gxor<G>(x, m));
+  return x;
+}
+// (value, index) arg-min with ties to the lower index (numpy argmin order on canonical rows)
+template <int G> __device__ __forceinline__ void gargmin(double& v, int& i) {
+#pragma unroll
+  for (int m = 1; m < G; m <<= 1) {
+    double ov = gxor<G>(v, m);
+    int oi = __shfl_xor(i, m, G);
+    bool take = (ov < v) || (ov == v && oi < i);
+    v = take ? ov : v;
+    i = take ? oi : i;
+  }
+}
+// sums over earlier / later stages of the same coordinate (lane stride 2), exclusive
+template <int G> __device__ __forceinline__ double prefix_excl2(double v, int lane) {
+  double s = v;
+#pragma unroll
+  for (int d = 2; d < G; d <<= 1) {
+    double t = gup<G>(s, d);
+    s += (lane >= d) ? t : 0.0;
+  }
+  return s - v;
+}
+template <int G> __device__ __forceinline__ double suffix_excl2(double v, int lane) {
+  double s = v;
+#pragma unroll
+  for (int d = 2; d < G; d <<= 1) {
+    double t = gdown<G>(s, d);
+    s += (lane + d < G) ? t : 0.0;
+  }
+  return s - v;
+}
+
+// ------------------------------------------------------------------------------------------
+// geometry: closest point on a convex ring, unit normal, inside flip (ObstaclesUtils.py:50-109)
+// contraction off so that comparisons see the same roundings as the CPU oracle
+// ------------------------------------------------------------------------------------------
+__device__ __noinline__ void closest_point_normal(const double* __restrict__ ring, int nv, double px, double py,
+                                                  double& cx, double& cy, double& ex, double& ey, bool& degenerate) {
+#pragma clang fp contract(off)
+  double best = INFINITY;
+  cx = NAN; cy = NAN;
+  degenerate = false;
+  bool inside = false;
+  double x0v = ring[2 * (nv - 1)], y0v = ring[2 * (nv - 1) + 1];
+  bool f0 = y0v >= py;
+  for (int i = 0; i < nv; ++i) {
+    double ax = ring[2 * i], ay = ring[2 * i + 1];
+    int i1 = (i + 1 == nv) ? 0 : i + 1;
+    double bx = ring[2 * i1], by = ring[2 * i1 + 1];
+    double dx = bx - ax, dy = by - ay;
+    double nrm = sqrt(dx * dx + dy * dy);
+    double den = nrm * nrm;                      // sqrt-then-square, ObstaclesUtils.py:81
+    if (den == 0.0) {
+      degenerate = true;
+    } else {
+      double t = ((px - ax) * dx + (py - ay) * dy) / den;
+      t = fmax(0.0, fmin(1.0, t));
+      double qx = ax + t * dx, qy = ay + t * dy;
+      double ux = qx - px, uy = qy - py;
+      double d = sqrt(ux * ux + uy * uy);
+      if (d < best) { best = d; cx = qx; cy = qy; }
+    }
+    // crossing test of edge (ring[i-1] -> ring[i]) with the +X ray (matplotlib Path.contains_point)
+    bool f1 = ay >= py;
+    if (f0 != f1) {
+      bool hit = ((ay - py) * (x0v - ax) >= (ax - px) * (y0v - ay)) == f1;
+      if (hit) inside = !inside;
+    }
+    x0v = ax; y0v = ay; f0 = f1;
+  }
+  double nx = px - cx, ny = py - cy;
+  double nn = sqrt(nx * nx + ny * ny);
+  if (!(nn > 0.0)) { degenerate = true; ex = 0.0; ey = 0.0; return; }
+  nx = nx / nn; ny = ny / nn;
+  if (inside) { nx = -nx; ny = -ny; }
+  ex = nx; ey = ny;
+}
+
+// ------------------------------------------------------------------------------------------
+// the step kernel
+// ------------------------------------------------------------------------------------------
+// local row slots of a lane
+constexpr int R_RU = 0, R_RL = 1, R_VU = 2, R_VL = 3, R_M = 4, R_CBF = 5;
+
+template <int G, int NOBS_L>
+__global__ __launch_bounds__(64) void plan_step_kernel(
+    KArgs P, long B, const double* __restrict__ state, const double* __restrict__ goal,
+    const int8_t* __restrict__ first_foot, const double* __restrict__ delta_in,
+    const double* __restrict__ obs_xy, const int32_t* __restrict__ obs_nv,
+    double* __restrict__ U, double* __restrict__ X, double* __restrict__ theta_out,
+    double* __restrict__ omega_out, double* __restrict__ obj_out, int32_t* __restrict__ status_out,
+    int32_t* __restrict__ iters_out, unsigned long long* __restrict__ active_out, double* __restrict__ c_eta) {
+  constexpr int NMAX = G / 2;          // stages a group can hold
+  constexpr int NV = G;                // variable slots (lanes)
+  constexpr int GPW = 64 / G;          // groups per wavefront
+  constexpr int NR = R_CBF + NOBS_L;   // local row slots
+  constexpr int MAXOBS = 2 * NOBS_L;
+  constexpr int MAXWORDS = 16;         // (9*16 + 17*50 + 63)/64 = 16
+
+  __shared__ double lds_obs[GPW][MAXOBS > 0 ? MAXOBS : 1][4];   // eta_x, eta_y, b = eta.c + delta, h0
+  __shared__ double lds_P[GPW][NMAX][2][2];                     // P_b blocks of the velocity part of K
+  __shared__ unsigned long long lds_act[GPW][MAXWORDS];
+  __shared__ int lds_flag[GPW];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (G - 1);
+  const int grp = tid / G;
+  const long prob_raw = (long)blockIdx.x * GPW + grp;
+  const bool valid = prob_raw < B;
+  const long pb = valid ? prob_raw : (B - 1);
+  const int N = P.N;
+  const int a = lane >> 1;             // stage index: variable = p_{a+1}
+  const int c = lane & 1;              // coordinate
+  const bool var_on = a < N;
+  const double sgn_a = (a & 1) ? -1.0 : 1.0;
+  const double kap = P.kappa;
+
+  // ---- inputs (every lane of the group reads the same 64 B: one broadcast transaction) -------
+  const double p0x = state[pb * 5 + 0], v0x = state[pb * 5 + 1];
+  const double p0y = state[pb * 5 + 2], v0y = state[pb * 5 + 3];
+  const double th0 = state[pb * 5 + 4];
+  const double gx = goal[pb * 2 + 0], gy = goal[pb * 2 + 1];
+  const double foot0 = (double)first_foot[pb];
+  const double delta = delta_in ? delta_in[pb] : 0.0;
+  const double p0c = c ? p0y : p0x, v0c = c ? v0y : v0x, gc = c ? gy : gx;
+
+  // ---- theta / omega (HumanoidMpc.py:137-160) -------------------------------------------------
+  const double psi = atan2(gy - p0y, gx - p0x);
+  double th_r = 0.0, th_v = 0.0, om_a = 0.0;
+  {
+    double th = th0;
+    if (valid && lane == 0) theta_out[pb * (N + 1)] = th0;
+    for (int k = 0; k < N; ++k) {
+      double w = fmin(fmax(psi - th, -P.omega_max), P.omega_max);
+      double thn = th + w * P.tau;
+      if (k == a) { th_r = th; th_v = thn; om_a = w; }
+      if (valid && lane == 0) { omega_out[pb * N + k] = w; theta_out[pb * (N + 1) + k + 1] = thn; }
+      th = thn;
+    }
+  }
+  double cr, sr, cv, sv;
+  sincos(th_r, &sr, &cr);
+  sincos(th_v, &sv, &cv);
+  const double foot_r = (a & 1) ? -foot0 : foot0;      // s_v[a]
+  const double foot_v = -foot_r;                        // s_v[a+1]
+  // row vectors: reach row of this lane rr.(dp), velocity row wv.(v)
+  const double rr0 = c ? -sr : cr, rr1 = c ? cr : sr;
+  const double wv0 = c ? -sv : cv, wv1 = c ? cv * foot_v : sv;
+
+  // ---- obstacles: c_j, eta_j at the current CoM (HumanoidMpc.py:296-319) ----------------------
+  if (lane == 0) lds_flag[grp] = 0;
+  __syncthreads();
+  if (MAXOBS > 0) {
+    for (int j = lane; j < P.n_obs; j += G) {
+      const long oidx = pb * P.n_obs + j;
+      const int nv = obs_nv[oidx];
+      double cx = 0, cy = 0, ex = 0, ey = 0, bb = 0, h0 = INFINITY;
+      if (nv > 0) {
+        bool degen;
+        closest_point_normal(obs_xy + oidx * P.nvert_max * 2, nv, p0x, p0y, cx, cy, ex, ey, degen);
+        const double ec = ex * cx + ey * cy;
+        bb = ec + delta;
+        h0 = (ex * p0x + ey * p0y) - ec - delta;
+        if (degen) atomicOr(&lds_flag[grp], 2);
+        else if (h0 < -P.k0_tol) atomicOr(&lds_flag[grp], 1);
+      } else {
+        ex = 0.0; ey = 0.0; bb = -INFINITY;   // marks an empty slot
+      }
+      lds_obs[grp][j][0] = ex; lds_obs[grp][j][1] = ey; lds_obs[grp][j][2] = bb; lds_obs[grp][j][3] = h0;
+      if (c_eta && valid) {
+        double* o = c_eta + oidx * 4;
+        o[0] = cx; o[1] = cy; o[2] = ex; o[3] = ey;
+      }
+    }
+  }
+  __syncthreads();
+  const int front_flag = lds_flag[grp];
+
+  // per-lane LDCBF rows: obstacle j = 2t + c
+  double oex[NOBS_L > 0 ? NOBS_L : 1], oey[NOBS_L > 0 ? NOBS_L : 1], ob[NOBS_L > 0 ? NOBS_L : 1];
+  bool pres[NR];
+#pragma unroll
+  for (int t = 0; t < NOBS_L; ++t) {
+    const int j = 2 * t + c;
+    const bool on = var_on && j < P.n_obs;
+    double e0 = 0, e1 = 0, b2 = -INFINITY;
+    if (j < P.n_obs) { e0 = lds_obs[grp][j][0]; e1 = lds_obs[grp][j][1]; b2 = lds_obs[grp][j][2]; }
+    pres[R_CBF + t] = on && (b2 != -INFINITY);
+    oex[t] = e0; oey[t] = e1; ob[t] = pres[R_CBF + t] ? b2 : 0.0;
+  }
+  pres[R_RU] = pres[R_RL] = pres[R_VU] = pres[R_VL] = var_on;
+  pres[R_M] = var_on && (c == 0);
+
+  // bounds of the non-LDCBF rows
+  const double hi_r = P.l_max[c], lo_r = P.l_min[c];
+  const double hi_v = P.v_max[c], lo_v = P.v_min[c];
+  const double hi_m = P.v_max[0] - P.alpha_over_pi * fabs(om_a);
+  // affine parts: reach r = rr.(p_{a+1} - p_a) + (c ? s_a*ell : 0); p_0 is a constant for a = 0
+  const double r_c = (c ? foot_r * P.ell : 0.0) - ((a == 0) ? (rr0 * p0x + rr1 * p0y) : 0.0);
+  // v_{a+1} = kappa x_a + 2 kappa (-1)^a sum_{j<a} (-1)^j x_j + (-1)^{a+1} (v_0 + kappa p_0)
+  const double vcx = -sgn_a * (v0x + kap * p0x), vcy = -sgn_a * (v0y + kap * p0y);
+  const double w_c = wv0 * vcx + wv1 * vcy;
+
+  int n_rows_l = 0;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) n_rows_l += pres[i] ? 1 : 0;
+  const double m_rows = gsum<G>((double)n_rows_l);
+
+  // ---- linear row maps -------------------------------------------------------------------------
+  // rows(x): lin[R_RU] = rr.(x_a - x_{a-1}); lin[R_VU] = wv.v_a(x); lin[R_CBF+t] = eta_t . x_a
+  auto rows_lin = [&](double x, double& r_lin, double& w_lin, double (&h_lin)[NOBS_L > 0 ? NOBS_L : 1]) {
+    const double xp = gxor<G>(x, 1);
+    const double xx = c ? xp : x, xy = c ? x : xp;
+    double pxx = gup<G>(xx, 2), pxy = gup<G>(xy, 2);
+    if (a == 0) { pxx = 0.0; pxy = 0.0; }
+    r_lin = rr0 * (xx - pxx) + rr1 * (xy - pxy);
+    const double ps = prefix_excl2<G>(sgn_a * x, lane);
+    const double vl = kap * x + 2.0 * kap * sgn_a * ps;
+    const double vlp = gxor<G>(vl, 1);
+    const double vx = c ? vlp : vl, vy = c ? vl : vlp;
+    w_lin = wv0 * vx + wv1 * vy;
+#pragma unroll
+    for (int t = 0; t < NOBS_L; ++t) h_lin[t] = oex[t] * xx + oey[t] * xy;
+  };
+  // (G^T w)_lane from direction weights: tr (reach dir), tv (velocity dir), wc[t] (LDCBF rows, g = -eta)
+  auto GT_apply = [&](double tr, double tv, const double (&wc)[NOBS_L > 0 ? NOBS_L : 1]) -> double {
+    const double trp = gxor<G>(tr, 1);
+    const double t0 = c ? trp : tr, t1 = c ? tr : trp;
+    const double reach_own = c ? (sr * t0 + cr * t1) : (cr * t0 - sr * t1);
+    double reach_next = gdown<G>(reach_own, 2);
+    if (a + 1 >= N) reach_next = 0.0;
+    double res = var_on ? (reach_own - reach_next) : 0.0;
+    const double tvp = gxor<G>(tv, 1);
+    const double u0 = c ? tvp : tv, u1 = c ? tv : tvp;
+    const double u = c ? (sv * u0 + cv * foot_v * u1) : (cv * u0 - sv * u1);
+    const double uu = var_on ? u : 0.0;
+    const double suf = suffix_excl2<G>(sgn_a * uu, lane);
+    res += kap * uu + 2.0 * kap * sgn_a * suf;
+    double ax = 0.0, ay = 0.0;
+#pragma unroll
+    for (int t = 0; t < NOBS_L; ++t) { ax += oex[t] * wc[t]; ay += oey[t] * wc[t]; }
+    const double recv = gxor<G>(c ? ax : ay, 1);
+    res -= (c ? ay : ax) + recv;
+    return var_on ? res : 0.0;
+  };
+
+  // ---- K = 2I + G^T D G (lane = row), Cholesky, solves ----------------------------------------
+  double Krow[NV];
+  double invd = 1.0;   // 1 / L[lane][lane]
+  // dr = d_RU + d_RL, dv = d_VU + d_VL (+ d_M), dc[t] = LDCBF row weights
+  auto form_K = [&](double dr, double dv, const double (&dc)[NOBS_L > 0 ? NOBS_L : 1]) {
+    const double drp = gxor<G>(dr, 1);
+    const double d0 = c ? drp : dr, d1 = c ? dr : drp;
+    // F = Rr^T diag(d0,d1) Rr, Rr = [[cr,sr],[-sr,cr]]; this lane keeps row c
+    const double F00 = cr * cr * d0 + sr * sr * d1, F01 = cr * sr * (d0 - d1), F11 = sr * sr * d0 + cr * cr * d1;
+    const double Fc0 = c ? F01 : F00, Fc1 = c ? F11 : F01;
+    const double dvp = gxor<G>(dv, 1);
+    const double e0 = c ? dvp : dv, e1 = c ? dv : dvp;
+    // E = Wv^T diag(e0,e1) Wv, Wv = [[cv,sv],[-sv,cv*s]]
+    const double E00 = cv * cv * e0 + sv * sv * e1, E01 = cv * sv * e0 - sv * cv * foot_v * e1, E11 = sv * sv * e0 + cv * cv * e1;
+    double Ec0 = c ? E01 : E00, Ec1 = c ? E11 : E01;
+    if (!var_on) { Ec0 = 0.0; Ec1 = 0.0; }
+    const double S0 = suffix_excl2<G>(Ec0, lane), S1 = suffix_excl2<G>(Ec1, lane);
+    const double k2 = kap * kap;
+    const double Pc0 = 2.0 * k2 * Ec0 + 4.0 * k2 * S0, Pc1 = 2.0 * k2 * Ec1 + 4.0 * k2 * S1;
+    lds_P[grp][a][c][0] = Pc0; lds_P[grp][a][c][1] = Pc1;
+    double cxx = 0.0, cxy = 0.0, cyy = 0.0;
+#pragma unroll
+    for (int t = 0; t < NOBS_L; ++t) { cxx += dc[t] * oex[t] * oex[t]; cxy += dc[t] * oex[t] * oey[t]; cyy += dc[t] * oey[t] * oey[t]; }
+    cxx += gxor<G>(cxx, 1); cxy += gxor<G>(cxy, 1); cyy += gxor<G>(cyy, 1);
+    const double Cc0 = c ? cxy : cxx, Cc1 = c ? cyy : cxy;
+    double Fn0 = gdown<G>(Fc0, 2), Fn1 = gdown<G>(Fc1, 2);       // F_{a+1}, row c
+    if (a + 1 >= N) { Fn0 = 0.0; Fn1 = 0.0; }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NMAX; ++b) {
+      double q0v, q1v;
+      if (b <= a) { q0v = Pc0; q1v = Pc1; } else { q0v = lds_P[grp][b][c][0]; q1v = lds_P[grp][b][c][1]; }
+      const double sg = ((a + b) & 1) ? -1.0 : 1.0;
+      double k0 = sg * q0v, k1 = sg * q1v;
+      if (b == a) {
+        k0 += (c ? 0.0 : 2.0) - k2 * Ec0 + Fc0 + Fn0 + Cc0;
+        k1 += (c ? 2.0 : 0.0) - k2 * Ec1 + Fc1 + Fn1 + Cc1;
+      } else if (b == a - 1) { k0 -= Fc0; k1 -= Fc1; }
+      else if (b == a + 1) { k0 -= Fn0; k1 -= Fn1; }
+      const bool on = var_on && (b < N);
+      Krow[2 * b] = on ? k0 : ((2 * b == lane) ? 2.0 : 0.0);
+      Krow[2 * b + 1] = on ? k1 : ((2 * b + 1 == lane) ? 2.0 : 0.0);
+    }
+    __syncthreads();
+  };
+  // right-looking Cholesky, full symmetric storage: afterwards Krow[j] = L[lane][j] (j <= lane)
+  // and L[j][lane] (j > lane).  Returns false on a non-positive pivot.
+  auto factor = [&]() -> bool {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const double pj = gshfl<G>(Krow[j], j);
+      ok = ok && (pj > 0.0);
+      const double is = 1.0 / sqrt(pj);
+      const double lij = Krow[j] * is;
+#pragma unroll
+      for (int cc = j + 1; cc < NV; ++cc) {
+        const double lcj = gshfl<G>(Krow[cc], j) * is;
+        if (lane > j) Krow[cc] = fma(-lij, lcj, Krow[cc]);
+        else if (lane == j) Krow[cc] = lcj;                // column j of L lives on lane j
+      }
+      if (lane >= j) Krow[j] = lij;
+      if (lane == j) invd = is;     // 1/L[j][j] = 1/sqrt(pj)
+    }
+    return ok;
+  };
+  auto solve = [&](double b) -> double {
+    // forward L y = b
+    double y = 0.0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const double yj = gshfl<G>(b * invd, j);
+      if (lane == j) y = yj;
+      if (lane > j) b = fma(-Krow[j], yj, b);
+    }
+    // backward L^T x = y
+    double x = 0.0;
+#pragma unroll
+    for (int j = NV - 1; j >= 0; --j) {
+      const double xj = gshfl<G>(y * invd, j);
+      if (lane == j) x = xj;
+      if (lane < j) y = fma(-Krow[j], xj, y);
+    }
+    return x;
+  };
+
+  // ---- interior point ---------------------------------------------------------------------------
+  double q = var_on ? p0c : 0.0;
+  double s[NR], z[NR], slk[NR];     // slack variable, multiplier, slack function value h - g.q
+  double hl[NOBS_L > 0 ? NOBS_L : 1];
+  auto slack_values = [&](double x) {
+    double r_lin, w_lin;
+    rows_lin(x, r_lin, w_lin, hl);
+    const double r = r_lin + r_c, w = w_lin + w_c;
+    slk[R_RU] = hi_r - r; slk[R_RL] = r - lo_r;
+    slk[R_VU] = hi_v - w; slk[R_VL] = w - lo_v;
+    slk[R_M] = hi_m - w;
+#pragma unroll
+    for (int t = 0; t < NOBS_L; ++t) slk[R_CBF + t] = hl[t] - ob[t];
+  };
+  // g_i . dx for every local row from the linear maps
+  auto rows_dir = [&](double dx, double (&dl)[NR]) {
+    double r_lin, w_lin;
+    rows_lin(dx, r_lin, w_lin, hl);
+    dl[R_RU] = r_lin; dl[R_RL] = -r_lin; dl[R_VU] = w_lin; dl[R_VL] = -w_lin; dl[R_M] = w_lin;
+#pragma unroll
+    for (int t = 0; t < NOBS_L; ++t) dl[R_CBF + t] = -hl[t];
+  };
+  auto GT_rows = [&](const double (&w)[NR]) -> double {
+    double wc[NOBS_L > 0 ? NOBS_L : 1];
+#pragma unroll
+    for (int t = 0; t < NOBS_L; ++t) wc[t] = w[R_CBF + t];
+    return GT_apply(w[R_RU] - w[R_RL], w[R_VU] - w[R_VL] + w[R_M], wc);
+  };
+  auto K_rows = [&](const double (&d)[NR]) {
+    double dc[NOBS_L > 0 ? NOBS_L : 1];
+#pragma unroll
+    for (int t = 0; t < NOBS_L; ++t) dc[t] = d[R_CBF + t];
+    form_K(d[R_RU] + d[R_RL], d[R_VU] + d[R_VL] + d[R_M], dc);
+  };
+
+  slack_values(q);
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    s[i] = pres[i] ? fmax(slk[i], IPM_S_FLOOR) : 1.0;
+    z[i] = pres[i] ? IPM_Z0 : 0.0;
+  }
+
+  int status = LIPMPC_STATUS_MAX_ITER;
+  int iters = 0;
+  bool done = false;
+  if (front_flag & 2) { status = LIPMPC_STATUS_DEGENERATE; done = true; }
+  else if (front_flag & 1) { status = LIPMPC_STATUS_INFEASIBLE; done = true; }
+  if (m_rows == 0.0 && !done) { status = LIPMPC_STATUS_SOLVED; done = true; q = var_on ? gc : 0.0; }
+
+  for (int it = 0; it <= P.max_iter; ++it) {
+    if (__all(done)) break;
+    double rp[NR], w[NR], d[NR];
+    slack_values(q);
+    double mu_l = 0.0, rpmax_l = 0.0, zmax_l = 0.0;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      rp[i] = pres[i] ? (s[i] - slk[i]) : 0.0;
+      mu_l += pres[i] ? s[i] * z[i] : 0.0;
+      rpmax_l = fmax(rpmax_l, fabs(rp[i]));
+      zmax_l = fmax(zmax_l, z[i]);
+    }
+    const double mu = gsum<G>(mu_l) / m_rows;
+    const double rpmax = gmax<G>(rpmax_l);
+    const double zmax = gmax<G>(zmax_l);
+    const bool bad = !(zmax < IPM_Z_DIVERGE) || !(gmax<G>(fabs(q)) < 1e300);
+    if (!done) {
+      if (rpmax <= P.tol && mu <= P.tol) { status = LIPMPC_STATUS_SOLVED; done = true; iters = it; }
+      else if (it == P.max_iter) { done = true; iters = it; }
+      else if (bad) { status = LIPMPC_STATUS_INFEASIBLE; done = true; iters = it; }
+    }
+    if (__all(done)) break;
+    // finished groups keep running with frozen state (step length 0) until the wave is done
+#pragma unroll
+    for (int i = 0; i < NR; ++i) d[i] = pres[i] ? z[i] / s[i] : 0.0;
+    K_rows(d);
+    const bool fok = factor();
+    if (!fok && !done) { status = LIPMPC_STATUS_INFEASIBLE; done = true; iters = it; }
+    const double gtz = GT_rows(z);
+    const double rd = var_on ? (2.0 * (q - gc) + gtz) : 0.0;
+    // predictor: rc = s z
+#pragma unroll
+    for (int i = 0; i < NR; ++i) w[i] = pres[i] ? (z[i] * rp[i] - s[i] * z[i]) / s[i] : 0.0;
+    double dq = solve(-rd - GT_rows(w));
+    double dl[NR], dsa[NR], dza[NR];
+    rows_dir(dq, dl);
+    double a_l = 1.0;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      dsa[i] = pres[i] ? (-rp[i] - dl[i]) : 0.0;
+      dza[i] = pres[i] ? -(s[i] * z[i] + z[i] * dsa[i]) / s[i] : 0.0;
+      if (dsa[i] < 0.0) a_l = fmin(a_l, -s[i] / dsa[i]);
+      if (dza[i] < 0.0) a_l = fmin(a_l, -z[i] / dza[i]);
+    }
+    const double a_aff = gmin<G>(a_l);
+    double mua_l = 0.0;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) mua_l += pres[i] ? (s[i] + a_aff * dsa[i]) * (z[i] + a_aff * dza[i]) : 0.0;
+    const double mu_aff = gsum<G>(mua_l) / m_rows;
+    const double ratio = mu_aff / mu;
+    const double sigma_mu = ratio * ratio * ratio * mu;
+    // corrector: rc = s z + ds_a dz_a - sigma mu
+    double rc[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      rc[i] = pres[i] ? (s[i] * z[i] + dsa[i] * dza[i] - sigma_mu) : 0.0;
+      w[i] = pres[i] ? (z[i] * rp[i] - rc[i]) / s[i] : 0.0;
+    }
+    dq = solve(-rd - GT_rows(w));
+    rows_dir(dq, dl);
+    a_l = 1.0 / IPM_STEP_FRAC;
+    double ds[NR], dz[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      ds[i] = pres[i] ? (-rp[i] - dl[i]) : 0.0;
+      dz[i] = pres[i] ? -(rc[i] + z[i] * ds[i]) / s[i] : 0.0;
+      if (ds[i] < 0.0) a_l = fmin(a_l, -s[i] / ds[i]);
+      if (dz[i] < 0.0) a_l = fmin(a_l, -z[i] / dz[i]);
+    }
+    double alpha = fmin(1.0, IPM_STEP_FRAC * gmin<G>(a_l));
+    if (done) alpha = 0.0;
+    q = fma(alpha, dq, q);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      if (pres[i] && !done) { s[i] = fma(alpha, ds[i], s[i]); z[i] = fma(alpha, dz[i], z[i]); }
+    }
+  }
+
+  // ---- certified active-set finish --------------------------------------------------------------
+  bool act[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) act[i] = pres[i] && (z[i] > s[i]);
+  const bool ipm_ok = (status == LIPMPC_STATUS_SOLVED) && (m_rows > 0.0);
+  if (!(P.flags & LIPMPC_FLAG_INTERIOR)) {
+    bool fin_done = !ipm_ok;        // groups that never converged skip the finish
+    bool certified = false;
+    double qf = q;
+    double y[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) y[i] = act[i] ? z[i] : 0.0;
+    // canonical row index of each local slot (argmin tie-break and the active mask)
+    for (int rnd = 0; rnd < FIN_ROUNDS; ++rnd) {
+      if (__all(fin_done)) break;
+      double d[NR];
+#pragma unroll
+      for (int i = 0; i < NR; ++i) d[i] = act[i] ? FIN_RHO : 0.0;
+      K_rows(d);
+      const bool fok = factor();
+      double eres = INFINITY;
+      for (int in = 0; in <= FIN_INNER; ++in) {
+        slack_values(qf);
+        double wr[NR], rmax_l = 0.0;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          const double r = act[i] ? -slk[i] : 0.0;      // G_A q - h_A
+          wr[i] = FIN_RHO * r;
+          rmax_l = fmax(rmax_l, fabs(r));
+        }
+        const double gty = GT_rows(y);
+        const double rd = var_on ? (2.0 * (qf - gc) + gty) : 0.0;
+        eres = fmax(gmax<G>(fabs(rd)), gmax<G>(rmax_l));
+        const bool stop = (eres <= FIN_INNER_TOL) || (in == FIN_INNER);
+        if (__all(stop || fin_done)) break;
+        const double dq = solve(-rd - GT_rows(wr));
+        double dl[NR];
+        rows_dir(dq, dl);
+        if (!stop && !fin_done) {
+          qf += dq;
+#pragma unroll
+          for (int i = 0; i < NR; ++i) if (act[i]) y[i] += FIN_RHO * (dl[i] - slk[i]);
+        }
+      }
+      slack_values(qf);
+      // most negative multiplier in A, most violated row outside A (lowest canonical index on ties)
+      double ymin = INFINITY, smin = INFINITY;
+      int yi = 0x7fffffff, si = 0x7fffffff;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        int ci;
+        if (i == R_RU) ci = 4 * a + c; else if (i == R_RL) ci = 4 * a + 2 + c;
+        else if (i == R_VU) ci = 5 * N + 4 * a + c; else if (i == R_VL) ci = 5 * N + 4 * a + 2 + c;
+        else if (i == R_M) ci = 4 * N + a; else ci = 9 * N + (a + 1) * P.n_obs + 2 * (i - R_CBF) + c;
+        if (act[i] && (y[i] < ymin || (y[i] == ymin && ci < yi))) { ymin = y[i]; yi = ci; }
+        if (pres[i] && !act[i] && (slk[i] < smin || (slk[i] == smin && ci < si))) { smin = slk[i]; si = ci; }
+      }
+      gargmin<G>(ymin, yi);
+      gargmin<G>(smin, si);
+      const double qabs = gmax<G>(fabs(qf));
+      if (!fin_done) {
+        if (ymin < -FIN_EPS) {
+#pragma unroll
+          for (int i = 0; i < NR; ++i) {
+            int ci;
+            if (i == R_RU) ci = 4 * a + c; else if (i == R_RL) ci = 4 * a + 2 + c;
+            else if (i == R_VU) ci = 5 * N + 4 * a + c; else if (i == R_VL) ci = 5 * N + 4 * a + 2 + c;
+            else if (i == R_M) ci = 4 * N + a; else ci = 9 * N + (a + 1) * P.n_obs + 2 * (i - R_CBF) + c;
+            if (act[i] && ci == yi) { act[i] = false; y[i] = 0.0; }
+          }
+        } else if (smin < -FIN_EPS) {
+#pragma unroll
+          for (int i = 0; i < NR; ++i) {
+            int ci;
+            if (i == R_RU) ci = 4 * a + c; else if (i == R_RL) ci = 4 * a + 2 + c;
+            else if (i == R_VU) ci = 5 * N + 4 * a + c; else if (i == R_VL) ci = 5 * N + 4 * a + 2 + c;
+            else if (i == R_M) ci = 4 * N + a; else ci = 9 * N + (a + 1) * P.n_obs + 2 * (i - R_CBF) + c;
+            if (pres[i] && !act[i] && ci == si) act[i] = true;
+          }
+        } else {
+          fin_done = true;
+          certified = fok && (eres <= FIN_EPS) && (qabs < 1e300);
+        }
+      }
+    }
+    if (ipm_ok) {
+      if (certified) {
+        q = qf;
+      } else {
+        status = LIPMPC_STATUS_UNCERTIFIED;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) act[i] = pres[i] && (z[i] > s[i]);
+      }
+    }
+  }
+
+  // ---- outputs -----------------------------------------------------------------------------------
+  const bool have_sol = (status == LIPMPC_STATUS_SOLVED) || (status == LIPMPC_STATUS_UNCERTIFIED);
+  // velocities v_{a+1} of the solution
+  const double ps = prefix_excl2<G>(sgn_a * q, lane);
+  const double vsol = kap * q + 2.0 * kap * sgn_a * ps - sgn_a * (v0c + kap * p0c);
+  double pprev = gup<G>(q, 2), vprev = gup<G>(vsol, 2);
+  if (a == 0) { pprev = p0c; vprev = v0c; }
+  const double u = (q - P.ch * pprev - P.sh_over_beta * vprev) * P.inv_one_minus_ch;
+  const double dg = var_on ? (q - gc) : 0.0;
+  const double objv = gsum<G>(dg * dg) + (p0x - gx) * (p0x - gx) + (p0y - gy) * (p0y - gy);
+  for (int wi = lane; wi < P.words; wi += G) lds_act[grp][wi] = 0ull;
+  __syncthreads();
+  if (have_sol) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      int ci;
+      if (i == R_RU) ci = 4 * a + c; else if (i == R_RL) ci = 4 * a + 2 + c;
+      else if (i == R_VU) ci = 5 * N + 4 * a + c; else if (i == R_VL) ci = 5 * N + 4 * a + 2 + c;
+      else if (i == R_M) ci = 4 * N + a; else ci = 9 * N + (a + 1) * P.n_obs + 2 * (i - R_CBF) + c;
+      if (act[i]) atomicOr(&lds_act[grp][ci >> 6], 1ull << (ci & 63));
+    }
+  }
+  __syncthreads();
+  if (valid) {
+    const double nanv = NAN;
+    if (var_on) {
+      double* Xo = X + (pb * (N + 1) + a + 1) * 4;
+      Xo[2 * c] = have_sol ? q : nanv;
+      Xo[2 * c + 1] = have_sol ? vsol : nanv;
+      U[(pb * N + a) * 2 + c] = have_sol ? u : nanv;
+    }
+    if (lane < 2) {
+      double* Xo = X + pb * (N + 1) * 4;
+      Xo[2 * lane] = have_sol ? p0c : nanv;
+      Xo[2 * lane + 1] = have_sol ? v0c : nanv;
+    }
+    if (lane == 0) {
+      obj_out[pb] = have_sol ? objv : nanv;
+      status_out[pb] = status;
+      iters_out[pb] = iters;
+    }
+    for (int wi = lane; wi < P.words; wi += G) active_out[pb * P.words + wi] = lds_act[grp][wi];
+  }
+}
+
+
+// host-side launcher of one instantiation (defined in lipmpc_inst.hip, one object per (G, NOBS_L))
+template <int G, int NOBS_L>
+void launch_plan_step(const KArgs& k, long B, const double* state, const double* goal, const int8_t* first_foot,
+                      const double* delta, const double* obs_xy, const int32_t* obs_nv, double* U, double* X,
+                      double* theta, double* omega, double* obj, int32_t* status, int32_t* iters,
+                      unsigned long long* active, double* c_eta, hipStream_t stream);
+
+}  // namespace lipmpc_dev

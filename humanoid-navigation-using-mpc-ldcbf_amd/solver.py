@@ -1,0 +1,172 @@
+"""Batched step solver: the Python face of the C ABI.  Tensors live on the GPU (torch is used
+only to own device memory and streams); every call is asynchronous on torch's current stream."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _lib
+
+STATUS_SOLVED, STATUS_MAX_ITER, STATUS_INFEASIBLE, STATUS_DEGENERATE, STATUS_UNCERTIFIED = 0, 1, 2, 3, 4
+FLAG_INTERIOR = 1
+
+
+@dataclass
+class LipMpcParams:
+    """Constants of the step problem; defaults are the reference's config.yml:2-17 and
+    HumanoidMpc.py:20-22,:200."""
+    N: int = 3
+    n_obs_max: int = 0
+    v_max: int = 5
+    max_iter: int = 60
+    flags: int = 0
+    dt: float = 0.4
+    g: float = 9.81
+    h_com: float = 1.0
+    alpha: float = 3.6
+    l_max: tuple = (0.10, 0.10)
+    l_min: tuple = (-0.1, -0.1)
+    v_min: tuple = (-0.1, 0.1)
+    v_max_xy: tuple = (0.8, 0.4)
+    omega_max: float = 0.156 * math.pi
+    ell: float = 0.05
+    sampling_time: float = 0.4
+    tol: float = 1e-9
+    k0_tol: float = 1e-5
+
+    def to_c(self):
+        p = _lib.LipmpcParamsC()
+        for f in ("N", "n_obs_max", "v_max", "max_iter", "flags"):
+            setattr(p, f, int(getattr(self, f)))
+        for f in ("dt", "g", "h_com", "alpha", "omega_max", "ell", "sampling_time", "tol", "k0_tol"):
+            setattr(p, f, float(getattr(self, f)))
+        for f in ("l_max", "l_min", "v_min", "v_max_xy"):
+            v = getattr(self, f)
+            setattr(p, f, (C.c_double * 2)(float(v[0]), float(v[1])))
+        return p
+
+    @property
+    def num_rows(self):
+        return 9 * self.N + (self.N + 1) * self.n_obs_max
+
+    @property
+    def active_words(self):
+        return (self.num_rows + 63) // 64
+
+
+def _ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class BatchedLipMpc:
+    """One handle = one (device, parameter set).  ``plan_step_batch`` solves B independent MPC
+    steps; ``advance`` applies the reference's state update to the states in place."""
+
+    def __init__(self, params: LipMpcParams, device: int | None = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("lipmpc needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
+        self.lib = _lib.load()
+        self.params = params
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self._h = C.c_void_p()
+        cp = params.to_c()
+        _lib.check(self.lib.lipmpc_create(C.byref(cp), self.device_index, C.byref(self._h)), "lipmpc_create")
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self.lib.lipmpc_destroy(h)
+            self._h = C.c_void_p()
+
+    # ---- buffers --------------------------------------------------------------------------------
+    def alloc_outputs(self, B, with_c_eta=False):
+        P, dev = self.params, self.device
+        f64 = dict(dtype=torch.float64, device=dev)
+        out = dict(
+            U=torch.empty((B, P.N, 2), **f64), X=torch.empty((B, P.N + 1, 4), **f64),
+            theta=torch.empty((B, P.N + 1), **f64), omega=torch.empty((B, P.N), **f64),
+            obj=torch.empty((B,), **f64),
+            status=torch.empty((B,), dtype=torch.int32, device=dev),
+            iters=torch.empty((B,), dtype=torch.int32, device=dev),
+            active=torch.empty((B, P.active_words), dtype=torch.int64, device=dev),
+        )
+        if with_c_eta:
+            out["c_eta"] = torch.empty((B, P.n_obs_max, 4), **f64)
+        return out
+
+    def _check_inputs(self, state, goal, first_foot, obs_xy, obs_nv, delta):
+        P = self.params
+        B = state.shape[0]
+
+        def need(t, shape, dtype, name):
+            if t is None:
+                raise ValueError(f"{name} is required")
+            if tuple(t.shape) != shape or t.dtype != dtype or t.device != self.device or not t.is_contiguous():
+                raise ValueError(f"{name}: expected contiguous {dtype} {shape} on {self.device}, got "
+                                 f"{t.dtype} {tuple(t.shape)} on {t.device}")
+        need(state, (B, 5), torch.float64, "state")
+        need(goal, (B, 2), torch.float64, "goal")
+        need(first_foot, (B,), torch.int8, "first_foot")
+        if P.n_obs_max > 0:
+            need(obs_xy, (B, P.n_obs_max, P.v_max, 2), torch.float64, "obs_xy")
+            need(obs_nv, (B, P.n_obs_max), torch.int32, "obs_nv")
+        if delta is not None:
+            need(delta, (B,), torch.float64, "delta")
+        return B
+
+    # ---- the hot path -----------------------------------------------------------------------------
+    def plan_step_batch(self, state, goal, first_foot, obs_xy=None, obs_nv=None, delta=None, out=None,
+                        with_c_eta=False):
+        """state [B,5] (px,vx,py,vy,theta), goal [B,2], first_foot [B] int8 (+1 right / -1 left),
+        obs_xy [B,n_obs_max,v_max,2] CCW rings, obs_nv [B,n_obs_max] int32, delta [B] or None.
+        Returns dict(U,X,theta,omega,obj,status,iters,active[,c_eta]) of device tensors; results are
+        valid once the current stream is synchronised."""
+        B = self._check_inputs(state, goal, first_foot, obs_xy, obs_nv, delta)
+        if out is None:
+            out = self.alloc_outputs(B, with_c_eta)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.lib.lipmpc_plan_step_batch(
+            self._h, B, _ptr(state), _ptr(goal), _ptr(first_foot), _ptr(delta), _ptr(obs_xy), _ptr(obs_nv),
+            _ptr(out["U"]), _ptr(out["X"]), _ptr(out["theta"]), _ptr(out["omega"]), _ptr(out["obj"]),
+            _ptr(out["status"]), _ptr(out["iters"]), _ptr(out["active"]), _ptr(out.get("c_eta")),
+            C.c_void_p(stream))
+        _lib.check(rc, "lipmpc_plan_step_batch")
+        return out
+
+    def advance(self, state, first_foot, out):
+        """In place: state <- (A_l x + B_l U[:,0], theta[:,1]), first_foot <- -first_foot for the
+        problems whose status is solved (HumanoidMpc.py:432-447)."""
+        B = state.shape[0]
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.lib.lipmpc_advance_batch(self._h, B, _ptr(state), _ptr(first_foot), _ptr(out["U"]),
+                                           _ptr(out["theta"]), _ptr(out["status"]), C.c_void_p(stream))
+        _lib.check(rc, "lipmpc_advance_batch")
+
+
+def unpack_active(active_words: np.ndarray, num_rows: int) -> np.ndarray:
+    """[B,words] int64/uint64 -> [B,num_rows] bool in canonical row order."""
+    w = np.ascontiguousarray(active_words).view(np.uint64)
+    bits = (w[:, :, None] >> np.arange(64, dtype=np.uint64)[None, None, :]) & np.uint64(1)
+    return bits.reshape(w.shape[0], -1)[:, :num_rows].astype(bool)
+
+
+def pack_rings(obstacle_sets, n_obs_max, v_max):
+    """list (per problem) of lists of (V,2) CCW rings -> (obs_xy [B,n_obs_max,v_max,2], obs_nv [B,n_obs_max])."""
+    B = len(obstacle_sets)
+    xy = np.zeros((B, n_obs_max, v_max, 2))
+    nv = np.zeros((B, n_obs_max), np.int32)
+    for b, rings in enumerate(obstacle_sets):
+        if len(rings) > n_obs_max:
+            raise ValueError(f"problem {b}: {len(rings)} obstacles > n_obs_max={n_obs_max}")
+        for j, r in enumerate(rings):
+            r = np.asarray(r, float)
+            if r.shape[0] > v_max:
+                raise ValueError(f"problem {b} obstacle {j}: {r.shape[0]} vertices > v_max={v_max}")
+            xy[b, j, : r.shape[0]] = r
+            nv[b, j] = r.shape[0]
+    return xy, nv

@@ -1,0 +1,120 @@
+/* lipmpc.h — C ABI of the MI355X-native batched LIP-MPC / LDCBF step solver.
+ *
+ * The reference (salvatore373/Humanoid-Navigation-using-MPC-LDCBF) is pure Python and has no
+ * FFI of its own; the boundary this library replaces is, per MPC step and per robot,
+ *
+ *   HumanoidMPC._precompute_theta_omega_naive      HumanoidNavigation/MPC/HumanoidMpc.py:137-160
+ *   HumanoidMPC._get_list_c_and_eta                HumanoidNavigation/MPC/HumanoidMpc.py:296-319
+ *     -> ObstaclesUtils.get_closest_point_and_normal_vector_from_obs
+ *                                                  HumanoidNavigation/Utils/ObstaclesUtils.py:60-109
+ *   HumanoidMPC._add_lcbf_constraint (+ CustomLCBF delta)
+ *                                                  HumanoidMpc.py:263-294, HumanoidMPCCustomLCBF.py:30-31
+ *   the constraint/cost definition                 HumanoidMpc.py:221-249, 321-333
+ *   self.optim_prob.solve()  (CasADi Opti + IPOPT) HumanoidMpc.py:97-100, 417-418
+ *   kth_solution.value(U_mpc[:,0]) / state advance HumanoidMpc.py:432-447
+ *
+ * batched over B independent (state, goal, obstacle-set) instances.  All pointers passed to
+ * lipmpc_plan_step_batch / lipmpc_advance_batch are DEVICE pointers (HIP, the handle's
+ * device); the caller owns every buffer; calls are asynchronous on `hip_stream` and results
+ * are valid after that stream is synchronised.  No function throws; return 0 = ok, <0 = error
+ * (lipmpc_strerror).  A handle is not thread-safe: one handle per (device, stream).
+ */
+#ifndef LIPMPC_H
+#define LIPMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIPMPC_ABI_VERSION 1
+
+/* per-problem status written to status[b] */
+#define LIPMPC_STATUS_SOLVED       0  /* exact optimum, KKT-certified active set */
+#define LIPMPC_STATUS_MAX_ITER     1  /* interior-point iteration cap reached */
+#define LIPMPC_STATUS_INFEASIBLE   2  /* no feasible step (incl. a violated constant k=0 LDCBF row);
+                                         the reference raises inside solve() here (HumanoidMpc.py:419-429) */
+#define LIPMPC_STATUS_DEGENERATE   3  /* x == c or zero-length edge: reference yields NaN (ObstaclesUtils.py:81,104) */
+#define LIPMPC_STATUS_UNCERTIFIED  4  /* interior-point tolerance met, active-set finish not certified */
+
+/* flags */
+#define LIPMPC_FLAG_INTERIOR 1  /* skip the active-set finish: return the strictly interior
+                                   interior-point iterate (what IPOPT hands the reference's loop) */
+
+/* error codes */
+#define LIPMPC_OK            0
+#define LIPMPC_E_ARG        -1
+#define LIPMPC_E_UNSUPPORTED -2
+#define LIPMPC_E_HIP        -3
+#define LIPMPC_E_NOMEM      -4
+
+typedef struct lipmpc_params {
+  int32_t N;            /* horizon, 1..16                         (N_horizon, HumanoidMpc.py:50) */
+  int32_t n_obs_max;    /* obstacle slots per problem, 0..50 */
+  int32_t v_max;        /* vertex slots per obstacle ring, 3..32 */
+  int32_t max_iter;     /* interior-point iteration cap */
+  int32_t flags;        /* LIPMPC_FLAG_* */
+  int32_t reserved;
+  double dt;            /* DELTA_T            config.yml:2  */
+  double g;             /* GRAVITY_CONST      config.yml:3  */
+  double h_com;         /* COM_HEIGHT         config.yml:4  */
+  double alpha;         /* ALPHA              config.yml:5  */
+  double l_max[2];      /* L_MAX_X, L_MAX_Y   config.yml:6-7 */
+  double l_min[2];      /* L_MIN_X, L_MIN_Y   config.yml:8-9 */
+  double v_min[2];      /* V_MIN              config.yml:10 */
+  double v_max_xy[2];   /* V_MAX              config.yml:11 */
+  double omega_max;     /* 0.156*pi           HumanoidMpc.py:21 */
+  double ell;           /* 0.05               HumanoidMpc.py:200 */
+  double sampling_time; /* theta update step  HumanoidMpc.py:159 */
+  double tol;           /* interior-point stop: max|r_p| <= tol and mu <= tol */
+  double k0_tol;        /* tolerated violation of the constant k=0 LDCBF rows (IPOPT constr_viol_tol, HumanoidMpc.py:99) */
+} lipmpc_params;
+
+typedef struct lipmpc_handle lipmpc_handle;
+
+/* fills *p with the reference's config.yml values, N=3, n_obs_max=0, v_max=5, tol=1e-9 */
+int lipmpc_default_params(lipmpc_params* p);
+
+int lipmpc_create(const lipmpc_params* p, int device, lipmpc_handle** out);
+void lipmpc_destroy(lipmpc_handle* h);
+
+/* number of inequality rows in canonical order reach(4N) | manoeuvr(N) | vel(4N) | LDCBF((N+1)*n_obs_max)
+ * (insertion order of HumanoidMpc.py:230-249, 284-292) and of 64-bit words of the active mask */
+int64_t lipmpc_num_rows(const lipmpc_params* p);
+int64_t lipmpc_active_words(const lipmpc_params* p);
+
+/* One MPC step for B problems.
+ *  state      [B,5]  (p_x, v_x, p_y, v_y, theta)            X_pred[:,k]      HumanoidMpc.py:396-397
+ *  goal       [B,2]                                          self.goal        HumanoidMpc.py:83
+ *  first_foot [B]    s_v of the current stance, +1 right / -1 left            HumanoidMpc.py:104-108,403
+ *  delta      [B] or NULL (=0)  LDCBF safety margin          HumanoidMPCCustomLCBF.py:30-31
+ *  obs_xy     [B,n_obs_max,v_max,2]  CCW rings hull.points[hull.vertices], padded
+ *  obs_nv     [B,n_obs_max]          vertices used per ring, 0 = slot empty
+ * outputs
+ *  U      [B,N,2]    footsteps U_mpc            X [B,N+1,4] predicted states X_mpc
+ *  theta  [B,N+1]    omega [B,N]                obj [B] objective incl. the constant k=0 term
+ *  status [B]  iters [B]  active [B,lipmpc_active_words]  bit i = canonical row i in the certified active set
+ *  c_eta  [B,n_obs_max,4] (c_x,c_y,eta_x,eta_y) or NULL
+ */
+int lipmpc_plan_step_batch(lipmpc_handle* h, int64_t B,
+                           const double* state, const double* goal, const int8_t* first_foot,
+                           const double* delta, const double* obs_xy, const int32_t* obs_nv,
+                           double* U, double* X, double* theta, double* omega, double* obj,
+                           int32_t* status, int32_t* iters, uint64_t* active, double* c_eta,
+                           void* hip_stream);
+
+/* Closed-loop state advance (HumanoidMpc.py:432-447): for problems with status SOLVED/UNCERTIFIED
+ * state <- (A_l x + B_l U[b,0], theta[b,1]), first_foot <- -first_foot; others are left untouched.
+ * In place on state/first_foot. */
+int lipmpc_advance_batch(lipmpc_handle* h, int64_t B, double* state, int8_t* first_foot,
+                         const double* U, const double* theta, const int32_t* status,
+                         void* hip_stream);
+
+const char* lipmpc_strerror(int code);
+int lipmpc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIPMPC_H */

@@ -387,7 +387,7 @@ def solve_qp_ipm(G, h, g, q0, tol=1e-9, max_iter=60):
             return dq, ds, dz
 
         dq_a, ds_a, dz_a = kkt_solve(s * z)
-        a_aff = min(_max_step(s, ds_a), _max_step(z, dz_a))
+        a_aff = min(1.0, _max_step(s, ds_a), _max_step(z, dz_a))
         mu_aff = float((s + a_aff * ds_a) @ (z + a_aff * dz_a)) / m
         sigma = (mu_aff / mu) ** 3
         dq, ds, dz = kkt_solve(s * z + ds_a * dz_a - sigma * mu)
@@ -399,10 +399,11 @@ def solve_qp_ipm(G, h, g, q0, tol=1e-9, max_iter=60):
 
 
 def _max_step(v, dv):
+    """largest a with v + a dv >= 0 (inf when nothing blocks)"""
     neg = dv < 0
     if not np.any(neg):
-        return 1.0
-    return min(1.0, float(np.min(-v[neg] / dv[neg])))
+        return math.inf
+    return float(np.min(-v[neg] / dv[neg]))
 
 
 def eqp_multiplier_method(G, h, g, active, q, y_full):

@@ -1,0 +1,179 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on
+identical inputs.  Tolerances: footsteps/CoM trajectories 1e-5 (north_star; observed ~1e-9),
+theta/omega 1e-12, c/eta 4e-15 (eta: /distance), status and active-set indices bit-exact
+(problems whose interior-point margin |log(z/s)| is below 0.5 are excluded from the bit-exact
+active-set comparison and counted)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+import lipmpc  # noqa: E402
+import lipmpc_oracle as O  # noqa: E402
+from helpers import closed_loop_problems, load_rings  # noqa: E402
+
+
+def _dev(a, dt):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device="cuda")
+
+
+def run_gpu(problems, N, n_obs_max, v_max, flags=0, with_c_eta=True, sampling_time=0.4):
+    P = lipmpc.LipMpcParams(N=N, n_obs_max=n_obs_max, v_max=v_max, flags=flags, sampling_time=sampling_time)
+    sv = lipmpc.BatchedLipMpc(P)
+    st = np.array([p[0] for p in problems])
+    goal = np.array([p[1] for p in problems], float)
+    foot = np.array([p[2] for p in problems], np.int8)
+    xy, nv = lipmpc.pack_rings([p[3] for p in problems], n_obs_max, v_max)
+    delta = np.array([p[4] for p in problems], float)
+    out = sv.plan_step_batch(_dev(st, torch.float64), _dev(goal, torch.float64), _dev(foot, torch.int8),
+                             _dev(xy, torch.float64) if n_obs_max else None,
+                             _dev(nv, torch.int32) if n_obs_max else None, _dev(delta, torch.float64),
+                             with_c_eta=with_c_eta and n_obs_max > 0)
+    torch.cuda.synchronize()
+    res = {k: v.cpu().numpy() for k, v in out.items()}
+    res["active_bits"] = lipmpc.unpack_active(res["active"], P.num_rows)
+    return res
+
+
+def compare(problems, res, N, exact=True, tol_u=1e-5):
+    P = O.Params(N=N)
+    worst_u = worst_x = 0.0
+    n_weak = n_act_cmp = 0
+    it_diff = 0
+    for b, (st, goal, s0, obs, delta) in enumerate(problems):
+        r = O.plan_step(st, goal, s0, obs, delta, P, exact=exact)
+        assert res["status"][b] == r["status"], (b, res["status"][b], r["status"])
+        assert np.max(np.abs(res["theta"][b] - r["theta"])) < 1e-12
+        assert np.max(np.abs(res["omega"][b] - r["omega"])) < 1e-12
+        if r["status"] not in (O.STATUS_SOLVED, O.STATUS_UNCERTIFIED):
+            assert np.all(np.isnan(res["U"][b]))
+            continue
+        du = np.max(np.abs(res["U"][b] - r["U"]))
+        dx = np.max(np.abs(res["X"][b] - r["X"]))
+        worst_u, worst_x = max(worst_u, du), max(worst_x, dx)
+        assert du < tol_u and dx < tol_u, (b, du, dx)
+        assert abs(res["obj"][b] - r["obj"]) < 1e-6 * max(1.0, abs(r["obj"]))
+        it_diff = max(it_diff, abs(int(res["iters"][b]) - r["iters"]))
+        if exact:
+            if r["margin"] < 0.5:
+                n_weak += 1
+            else:
+                n_act_cmp += 1
+                assert np.array_equal(res["active_bits"][b], r["active"]), (b, np.where(res["active_bits"][b] != r["active"]))
+    return dict(worst_u=worst_u, worst_x=worst_x, n_weak=n_weak, n_act_cmp=n_act_cmp, it_diff=it_diff)
+
+
+def test_smoke_single_problem_no_obstacles():
+    probs = [(np.array([0.0, 0, 0.0, 0, 0.0]), (5.0, 5.0), 1, [], 0.0)]
+    res = run_gpu(probs, 3, 0, 5)
+    s = compare(probs, res, 3)
+    assert s["worst_u"] < 1e-8
+
+
+@pytest.mark.parametrize("N,n_obs,ntraj,steps", [(3, 3, 6, 25), (5, 3, 4, 20), (8, 10, 6, 25)])
+def test_closed_loop_states_match_oracle(N, n_obs, ntraj, steps):
+    probs = list(closed_loop_problems(N, n_obs, ntraj, steps, seed=100 + N))
+    assert len(probs) > 50
+    res = run_gpu(probs, N, n_obs, 5)
+    s = compare(probs, res, N)
+    print("parity", N, n_obs, len(probs), s)
+    assert s["worst_u"] < 1e-7 and s["it_diff"] <= 1
+    assert s["n_act_cmp"] > 0.8 * len(probs)
+
+
+def test_reference_generator_fields_config2(golden_dir):
+    """BASELINE config 2 inputs: obstacle fields produced by the reference's own generate_obstacles
+    (fixture fields_cfg2.npz), N=8, 10 obstacles, delta in {0, 0.3}."""
+    d = np.load(os.path.join(golden_dir, "fields_cfg2.npz"))
+    fields = [[d["rings"][f][j][: d["nv"][f][j]] for j in range(10)] for f in range(24)]
+    probs = []
+    for delta, sl in [(0.0, slice(0, 12)), (0.3, slice(12, 24))]:
+        probs += list(closed_loop_problems(8, 10, 12, 16, seed=7, delta=delta, fields=fields[sl]))
+    res = run_gpu(probs, 8, 10, 5)
+    s = compare(probs, res, 8)
+    print("cfg2 parity", len(probs), s)
+    assert s["worst_u"] < 1e-7
+
+
+def test_interior_flag_matches_oracle_ipm():
+    probs = list(closed_loop_problems(8, 10, 3, 20, seed=3))
+    res = run_gpu(probs, 8, 10, 5, flags=lipmpc.FLAG_INTERIOR)
+    s = compare(probs, res, 8, exact=False)
+    assert s["worst_u"] < 1e-6
+
+
+def test_geometry_golden_through_c_eta(golden_dir):
+    """c, eta of the kernel's front end against the REFERENCE's own outputs (geometry_golden.npz)."""
+    d = np.load(os.path.join(golden_dir, "geometry_golden.npz"))
+    probs = []
+    for q, w in zip(d["pts"], d["which"]):
+        ring = d["rings"][w][: d["nv"][w]]
+        probs.append((np.array([q[0], 0.0, q[1], 0.0, 0.0]), (q[0] + 5.0, q[1] + 5.0), 1, [ring], 0.0))
+    res = run_gpu(probs, 3, 1, 24)
+    ce = res["c_eta"][:, 0, :]
+    assert np.max(np.abs(ce[:, :2] - d["c"])) <= 4e-15
+    dist = np.hypot(d["pts"][:, 0] - d["c"][:, 0], d["pts"][:, 1] - d["c"][:, 1])
+    assert np.all(np.max(np.abs(ce[:, 2:] - d["eta"]), axis=1) <= 2e-15 + 4e-15 / dist)
+    # inside flag = sign of eta.(x - c): reference flips eta for inside points -> the k=0 row is negative
+    h0 = np.sum(ce[:, 2:] * (d["pts"] - ce[:, :2]), axis=1)
+    assert np.array_equal(h0 < 0, d["inside"])
+    # and bit-for-bit against the oracle's ring-order restatement
+    for b in range(0, len(probs), 7):
+        c2, e2, _, _ = O.closest_point_and_normal(d["pts"][b], probs[b][3][0])
+        assert np.array_equal(ce[b, :2], c2) and np.array_equal(ce[b, 2:], e2)
+
+
+def test_status_codes_and_empty_slots():
+    sq = np.array([[1.0, 1.0], [2.0, 1.0], [2.0, 2.0], [1.0, 2.0]])
+    far = np.array([[7.0, 7.0], [8.0, 7.0], [7.5, 8.0]])
+    probs = [
+        (np.array([1.5, 0, 1.4, 0, 0.0]), (5.0, 5.0), 1, [sq, far], 0.0),     # inside -> infeasible
+        (np.array([1.0, 0, 1.0, 0, 0.0]), (5.0, 5.0), 1, [sq, far], 0.0),     # on a vertex -> degenerate
+        (np.array([0.0, 0, 0.0, 0, 0.0]), (5.0, 5.0), -1, [far], 0.0),        # one empty slot
+        (np.array([0.0, 0, 0.0, 0, 0.0]), (5.0, 5.0), 1, [np.array([[1.0, 1], [1, 1], [2, 2]]), far], 0.0),
+    ]
+    res = run_gpu(probs, 3, 2, 5)
+    assert list(res["status"]) == [2, 3, 0, 3]
+    P = O.Params(N=3)
+    r = O.plan_step(probs[2][0], probs[2][1], -1, [far], 0.0, P)
+    assert np.max(np.abs(res["U"][2] - r["U"])) < 1e-8
+    # canonical indices of the present obstacle's rows follow n_obs_max = 2 slots
+    act = res["active_bits"][2]
+    ora = np.zeros(P.N * 9 + 4 * 2, bool)
+    ora[: 9 * 3] = r["active"][: 9 * 3]
+    for k in range(4):
+        ora[27 + 2 * k] = r["active"][27 + k]
+    assert np.array_equal(act, ora)
+
+
+def test_api_errors():
+    import ctypes as C
+    lib = lipmpc._lib.load()
+    p = lipmpc.LipMpcParams(N=40).to_c()
+    h = C.c_void_p()
+    assert lib.lipmpc_create(C.byref(p), 0, C.byref(h)) == -2
+    assert b"unsupported" in lib.lipmpc_strerror(-2)
+    sv = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=3))
+    with pytest.raises(ValueError):
+        sv.plan_step_batch(torch.zeros((2, 5)), torch.zeros((2, 2)), torch.zeros(2, dtype=torch.int8))
+
+
+def test_compat_class_closed_loop(golden_dir):
+    """HumanoidMPC drop-in on the reference's circles scenario (simulation_1.py:85-102): same first
+    steps as the PDF-recovered reference run, same run length as the oracle loop."""
+    obs = load_rings(os.path.join(golden_dir, "scenario_circles.npz"))
+    mpc = lipmpc.HumanoidMPC(goal=(6, -3), obstacles=obs, N_horizon=3, N_mpc_timesteps=300, sampling_time=0.4,
+                             init_state=(0, 0, 3, 0, 0), verbosity=0)
+    X, U, anim = mpc.run_simulation(path_to_gif=None, make_fast_plot=False, plot_animation=False, fill_animator=False)
+    assert anim is None and X.shape[0] == 5 and U.shape[0] == 3 and X.shape[1] == U.shape[1] + 1
+    pdf = np.load(os.path.join(golden_dir, "pdf_series.npz"))
+    ex = pdf["Simulation1Circles/ev0/s0"][:, 1] + 6.0
+    assert abs(X.shape[1] - len(ex)) <= 3
+    assert np.max(np.abs(X[0, :3] - ex[:3])) < 5e-7
+    Xo, Uo = O.run_closed_loop((6, -3), obs, N_horizon=3, N_mpc_timesteps=300, sampling_time=0.4,
+                               init_state=(0, 0, 3, 0, 0), exact=False)
+    n = min(10, Xo.shape[1], X.shape[1])
+    assert np.max(np.abs(X[:, :n] - Xo[:, :n])) < 1e-5
