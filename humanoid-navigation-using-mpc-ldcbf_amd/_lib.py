@@ -48,7 +48,7 @@ def load():
     lib.lipmpc_num_rows.restype = i64
     lib.lipmpc_active_words.argtypes = [C.POINTER(LipmpcParamsC)]
     lib.lipmpc_active_words.restype = i64
-    lib.lipmpc_plan_step_batch.argtypes = [vp, i64] + [vp] * 16
+    lib.lipmpc_plan_step_batch.argtypes = [vp, i64] + [vp] * 17
     lib.lipmpc_plan_step_batch.restype = i32
     lib.lipmpc_advance_batch.argtypes = [vp, i64] + [vp] * 6
     lib.lipmpc_advance_batch.restype = i32

@@ -85,12 +85,12 @@ void lipmpc_destroy(lipmpc_handle* h) { free(h); }
 
 #define LAUNCH(GG, NL)                                                                                         \
   launch_plan_step<GG, NL>(h->k, (long)B, state, goal, first_foot, delta, obs_xy, obs_nv, U, X, theta, omega, obj, \
-                           status, iters, (unsigned long long*)active, c_eta, stream)
+                           status, iters, (unsigned long long*)active, c_eta, diag, stream)
 
 int lipmpc_plan_step_batch(lipmpc_handle* h, int64_t B, const double* state, const double* goal,
                            const int8_t* first_foot, const double* delta, const double* obs_xy,
                            const int32_t* obs_nv, double* U, double* X, double* theta, double* omega,
-                           double* obj, int32_t* status, int32_t* iters, uint64_t* active, double* c_eta,
+                           double* obj, int32_t* status, int32_t* iters, uint64_t* active, double* c_eta, double* diag,
                            void* hip_stream) {
   if (!h || B < 0) return LIPMPC_E_ARG;
   if (B == 0) return LIPMPC_OK;

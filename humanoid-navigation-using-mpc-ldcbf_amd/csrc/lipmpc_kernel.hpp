@@ -36,6 +36,7 @@ constexpr double IPM_S_FLOOR = 0.1;
 constexpr double IPM_Z0 = 30.0;
 constexpr double IPM_STEP_FRAC = 0.995;
 constexpr double IPM_Z_DIVERGE = 1e13;
+constexpr double IPM_STALL_TOL = 1e-6;   // Cholesky breakdown below this (r_p, mu) counts as converged
 constexpr double FIN_RHO = 1e10;
 constexpr double FIN_EPS = 1e-9;
 constexpr int FIN_ROUNDS = 8;
@@ -163,7 +164,8 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
     const double* __restrict__ obs_xy, const int32_t* __restrict__ obs_nv,
     double* __restrict__ U, double* __restrict__ X, double* __restrict__ theta_out,
     double* __restrict__ omega_out, double* __restrict__ obj_out, int32_t* __restrict__ status_out,
-    int32_t* __restrict__ iters_out, unsigned long long* __restrict__ active_out, double* __restrict__ c_eta) {
+    int32_t* __restrict__ iters_out, unsigned long long* __restrict__ active_out, double* __restrict__ c_eta,
+    double* __restrict__ diag) {
   constexpr int NMAX = G / 2;          // stages a group can hold
   constexpr int NV = G;                // variable slots (lanes)
   constexpr int GPW = 64 / G;          // groups per wavefront
@@ -480,7 +482,12 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
     for (int i = 0; i < NR; ++i) d[i] = pres[i] ? z[i] / s[i] : 0.0;
     K_rows(d);
     const bool fok = factor();
-    if (!fok && !done) { status = LIPMPC_STATUS_INFEASIBLE; done = true; iters = it; }
+    if (!fok && !done) {
+      // K loses numerical definiteness once max(z/s) ~ 1e15: near the solution that is
+      // "converged to working precision" (the finish takes over), elsewhere infeasibility
+      status = (rpmax <= IPM_STALL_TOL && mu <= IPM_STALL_TOL) ? LIPMPC_STATUS_SOLVED : LIPMPC_STATUS_INFEASIBLE;
+      done = true; iters = it;
+    }
     const double gtz = GT_rows(z);
     const double rd = var_on ? (2.0 * (q - gc) + gtz) : 0.0;
     // predictor: rc = s z
@@ -523,13 +530,22 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
       if (dz[i] < 0.0) a_l = fmin(a_l, -z[i] / dz[i]);
     }
     double alpha = fmin(1.0, IPM_STEP_FRAC * gmin<G>(a_l));
-    if (done) alpha = 0.0;
-    q = fma(alpha, dq, q);
+    if (!done) q = fma(alpha, dq, q);      // (a finished group's dq may be non-finite: never touch its q)
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       if (pres[i] && !done) { s[i] = fma(alpha, ds[i], s[i]); z[i] = fma(alpha, dz[i], z[i]); }
     }
   }
+
+  // diagnostics: identification margin min |log(z/s)| and final mu of the interior-point phase
+  double marg_l = INFINITY, mufin_l = 0.0;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    if (pres[i]) { marg_l = fmin(marg_l, fabs(log(z[i] / s[i]))); mufin_l += s[i] * z[i]; }
+  }
+  const double margin = gmin<G>(marg_l);
+  const double mu_fin = gsum<G>(mufin_l) / fmax(m_rows, 1.0);
+  double diag_rounds = 0.0, diag_eres = 0.0;
 
   // ---- certified active-set finish --------------------------------------------------------------
   bool act[NR];
@@ -614,6 +630,8 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
           fin_done = true;
           certified = fok && (eres <= FIN_EPS) && (qabs < 1e300);
         }
+        diag_rounds = rnd + 1;
+        diag_eres = eres;
       }
     }
     if (ipm_ok) {
@@ -667,6 +685,7 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
       obj_out[pb] = have_sol ? objv : nanv;
       status_out[pb] = status;
       iters_out[pb] = iters;
+      if (diag) { diag[pb * 4 + 0] = diag_rounds; diag[pb * 4 + 1] = diag_eres; diag[pb * 4 + 2] = margin; diag[pb * 4 + 3] = mu_fin; }
     }
     for (int wi = lane; wi < P.words; wi += G) active_out[pb * P.words + wi] = lds_act[grp][wi];
   }
@@ -678,6 +697,6 @@ template <int G, int NOBS_L>
 void launch_plan_step(const KArgs& k, long B, const double* state, const double* goal, const int8_t* first_foot,
                       const double* delta, const double* obs_xy, const int32_t* obs_nv, double* U, double* X,
                       double* theta, double* omega, double* obj, int32_t* status, int32_t* iters,
-                      unsigned long long* active, double* c_eta, hipStream_t stream);
+                      unsigned long long* active, double* c_eta, double* diag, hipStream_t stream);
 
 }  // namespace lipmpc_dev

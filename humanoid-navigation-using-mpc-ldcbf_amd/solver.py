@@ -84,7 +84,7 @@ class BatchedLipMpc:
             self._h = C.c_void_p()
 
     # ---- buffers --------------------------------------------------------------------------------
-    def alloc_outputs(self, B, with_c_eta=False):
+    def alloc_outputs(self, B, with_c_eta=False, with_diag=False):
         P, dev = self.params, self.device
         f64 = dict(dtype=torch.float64, device=dev)
         out = dict(
@@ -97,6 +97,8 @@ class BatchedLipMpc:
         )
         if with_c_eta:
             out["c_eta"] = torch.empty((B, P.n_obs_max, 4), **f64)
+        if with_diag:
+            out["diag"] = torch.empty((B, 4), **f64)
         return out
 
     def _check_inputs(self, state, goal, first_foot, obs_xy, obs_nv, delta):
@@ -121,20 +123,20 @@ class BatchedLipMpc:
 
     # ---- the hot path -----------------------------------------------------------------------------
     def plan_step_batch(self, state, goal, first_foot, obs_xy=None, obs_nv=None, delta=None, out=None,
-                        with_c_eta=False):
+                        with_c_eta=False, with_diag=False):
         """state [B,5] (px,vx,py,vy,theta), goal [B,2], first_foot [B] int8 (+1 right / -1 left),
         obs_xy [B,n_obs_max,v_max,2] CCW rings, obs_nv [B,n_obs_max] int32, delta [B] or None.
         Returns dict(U,X,theta,omega,obj,status,iters,active[,c_eta]) of device tensors; results are
         valid once the current stream is synchronised."""
         B = self._check_inputs(state, goal, first_foot, obs_xy, obs_nv, delta)
         if out is None:
-            out = self.alloc_outputs(B, with_c_eta)
+            out = self.alloc_outputs(B, with_c_eta, with_diag)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = self.lib.lipmpc_plan_step_batch(
             self._h, B, _ptr(state), _ptr(goal), _ptr(first_foot), _ptr(delta), _ptr(obs_xy), _ptr(obs_nv),
             _ptr(out["U"]), _ptr(out["X"]), _ptr(out["theta"]), _ptr(out["omega"]), _ptr(out["obj"]),
             _ptr(out["status"]), _ptr(out["iters"]), _ptr(out["active"]), _ptr(out.get("c_eta")),
-            C.c_void_p(stream))
+            _ptr(out.get("diag")), C.c_void_p(stream))
         _lib.check(rc, "lipmpc_plan_step_batch")
         return out
 

@@ -96,12 +96,14 @@ int64_t lipmpc_active_words(const lipmpc_params* p);
  *  theta  [B,N+1]    omega [B,N]                obj [B] objective incl. the constant k=0 term
  *  status [B]  iters [B]  active [B,lipmpc_active_words]  bit i = canonical row i in the certified active set
  *  c_eta  [B,n_obs_max,4] (c_x,c_y,eta_x,eta_y) or NULL
+ *  diag   [B,4] or NULL: (active-set rounds used, final equality residual of the finish,
+ *         identification margin min_i |log(z_i/s_i)| of the interior-point phase, final mu)
  */
 int lipmpc_plan_step_batch(lipmpc_handle* h, int64_t B,
                            const double* state, const double* goal, const int8_t* first_foot,
                            const double* delta, const double* obs_xy, const int32_t* obs_nv,
                            double* U, double* X, double* theta, double* omega, double* obj,
-                           int32_t* status, int32_t* iters, uint64_t* active, double* c_eta,
+                           int32_t* status, int32_t* iters, uint64_t* active, double* c_eta, double* diag,
                            void* hip_stream);
 
 /* Closed-loop state advance (HumanoidMpc.py:432-447): for problems with status SOLVED/UNCERTIFIED

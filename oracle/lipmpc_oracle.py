@@ -337,6 +337,7 @@ IPM_S_FLOOR = 0.1      # initial slack floor
 IPM_Z0 = 30.0          # initial multiplier
 IPM_STEP_FRAC = 0.995  # fraction to the boundary
 IPM_Z_DIVERGE = 1e13   # multiplier blow-up => infeasible
+IPM_STALL_TOL = 1e-6   # Cholesky breakdown below this (r_p, mu) counts as converged
 FIN_RHO = 1e10         # penalty of the active-set equality solve
 FIN_EPS = 1e-9         # sign / violation threshold of the certificate
 FIN_ROUNDS = 8         # max add/drop rounds
@@ -375,7 +376,11 @@ def solve_qp_ipm(G, h, g, q0, tol=1e-9, max_iter=60):
         try:
             L = np.linalg.cholesky(K)
         except np.linalg.LinAlgError:
-            status = STATUS_INFEASIBLE
+            # K = 2I + G^T D G stops being numerically positive definite once max(z/s) ~ 1e15.
+            # Close to the solution that is "converged to working precision" (the finish takes
+            # over); anywhere else it is the signature of an infeasible problem.
+            near = np.max(np.abs(rp)) <= IPM_STALL_TOL and mu <= IPM_STALL_TOL
+            status = STATUS_SOLVED if near else STATUS_INFEASIBLE
             break
 
         def kkt_solve(rc):

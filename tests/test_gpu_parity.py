@@ -31,7 +31,7 @@ def run_gpu(problems, N, n_obs_max, v_max, flags=0, with_c_eta=True, sampling_ti
     out = sv.plan_step_batch(_dev(st, torch.float64), _dev(goal, torch.float64), _dev(foot, torch.int8),
                              _dev(xy, torch.float64) if n_obs_max else None,
                              _dev(nv, torch.int32) if n_obs_max else None, _dev(delta, torch.float64),
-                             with_c_eta=with_c_eta and n_obs_max > 0)
+                             with_c_eta=with_c_eta and n_obs_max > 0, with_diag=True)
     torch.cuda.synchronize()
     res = {k: v.cpu().numpy() for k, v in out.items()}
     res["active_bits"] = lipmpc.unpack_active(res["active"], P.num_rows)
@@ -99,10 +99,20 @@ def test_reference_generator_fields_config2(golden_dir):
 
 
 def test_interior_flag_matches_oracle_ipm():
+    """FLAG_INTERIOR returns the interior-point iterate (no finish).  That point is only defined up
+    to the stop tolerance: |q - q*| <= sqrt(m mu) ~ 4e-4 in weakly determined directions, and a
+    one-iteration difference between two correct implementations moves it by that much; so the
+    bound here is the iterate's own accuracy, not the 1e-5 of the exact path."""
     probs = list(closed_loop_problems(8, 10, 3, 20, seed=3))
     res = run_gpu(probs, 8, 10, 5, flags=lipmpc.FLAG_INTERIOR)
-    s = compare(probs, res, 8, exact=False)
-    assert s["worst_u"] < 1e-6
+    s = compare(probs, res, 8, exact=False, tol_u=4e-4)
+    # strictly interior: every predicted CoM keeps a positive LDCBF value
+    P = O.Params(N=8)
+    for b, (st, goal, s0, obs, delta) in enumerate(probs):
+        r = O.plan_step(st, goal, s0, obs, delta, P, exact=False)
+        p = res["X"][b][1:, [0, 2]]
+        for c, eta in zip(r["c"], r["eta"]):
+            assert np.all((p - c) @ eta - delta > 0.0)
 
 
 def test_geometry_golden_through_c_eta(golden_dir):
