@@ -68,8 +68,13 @@ def main():
     obs_xy = torch.as_tensor(xy, device=dev)
     obs_nv = torch.as_tensor(nv, device=dev)
     goal = torch.tensor([goal_xy], dtype=torch.float64, device=dev).repeat(B, 1).contiguous()
+    # delta = 0 and 0.3 variants; 0.3 only where the start keeps that clearance
+    st0 = torch.zeros((B, 5), dtype=torch.float64, device=dev)
+    ft0 = torch.ones((B,), dtype=torch.int8, device=dev)
+    ce = walker.plan_step_batch(st0, goal, ft0, obs_xy, obs_nv, None, with_c_eta=True)["c_eta"]
+    clear = torch.where(obs_nv > 0, torch.linalg.norm(ce[:, :, :2], dim=2), torch.full_like(ce[:, :, 0], 1e9)).min(dim=1).values
     delta = torch.zeros((B,), dtype=torch.float64, device=dev)
-    delta[B // 2:] = 0.3                                   # delta = 0 and 0.3 variants
+    delta[B // 2:] = torch.where(clear[B // 2:] > 0.45, 0.3, 0.0)
     state, foot = synth.walk_states(walker, obs_xy, obs_nv, goal, 30, seed=99 + rank, delta=delta)
     out = solver.alloc_outputs(B)
     torch.cuda.synchronize(dev)
@@ -168,6 +173,13 @@ def cpu_baseline(P, state, goal, foot, obs_xy, obs_nv, delta, out):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    try:  # a container's CPU quota (cgroup v2) is the real core budget
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    cores = min(cores, 64)
     B = st.shape[0]
     t0 = time.perf_counter()
     r1 = c_oracle.plan_step_batch(P, st, go, fo, xy, nv, de, n_threads=1)
