@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 #include "../../include/lipmpc.h"
 #pragma once
@@ -52,57 +53,108 @@ struct KArgs {
 };
 
 // ------------------------------------------------------------------------------------------
-// group-level communication (G lanes, G in {16, 32}); v1 uses the LDS crossbar (ds_bpermute)
+// group-level communication (G lanes, G in {16, 32}).
+// G = 16: a group is exactly one DPP row, so every exchange is a VALU DPP move (no LDS crossbar):
+//   broadcast of lane j      v_mov_b64_dpp row_newbcast:j
+//   xor 1 / 2                quad_perm, xor 4: row_shl:4 / row_shr:4 under bank masks, xor 8: row_ror:8
+//   shift by 2/4/8 stages    row_shr / row_shl with zero fill
+// G = 32 (two rows): in-row steps by DPP, cross-row steps through ds_bpermute.
 // ------------------------------------------------------------------------------------------
-template <int G> __device__ __forceinline__ double gshfl(double x, int src) { return __shfl(x, src, G); }
-template <int G> __device__ __forceinline__ double gxor(double x, int m) { return __shfl_xor(x, m, G); }
-template <int G> __device__ __forceinline__ double gup(double x, int d) { return __shfl_up(x, d, G); }
-template <int G> __device__ __forceinline__ double gdown(double x, int d) { return __shfl_down(x, d, G); }
+template <int I, int E, class F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < E) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, E>(f);
+  }
+}
+template <int I, int E, class F> __device__ __forceinline__ void static_rfor(F&& f) {   // I-1 down to E
+  if constexpr (I > E) {
+    f(std::integral_constant<int, I - 1>{});
+    static_rfor<I - 1, E>(f);
+  }
+}
+
+template <int CTRL, int BANK = 0xf, class T> __device__ __forceinline__ T dpp0(T x) {     // invalid source -> 0
+  return __builtin_amdgcn_update_dpp((T)0, x, CTRL, 0xf, BANK, true);
+}
+template <int M, class T> __device__ __forceinline__ T row_xor(T x) {
+  if constexpr (M == 1) return dpp0<0xB1>(x);                 // quad_perm [1,0,3,2]
+  else if constexpr (M == 2) return dpp0<0x4E>(x);            // quad_perm [2,3,0,1]
+  else if constexpr (M == 4) {
+    T r = __builtin_amdgcn_update_dpp((T)0, x, 0x104, 0xf, 0x5, false);   // banks 0,2 <- lane+4
+    return __builtin_amdgcn_update_dpp(r, x, 0x114, 0xf, 0xA, false);     // banks 1,3 <- lane-4
+  } else return dpp0<0x128>(x);                               // row_ror:8
+}
+template <int G, int M, class T> __device__ __forceinline__ T gxor(T x) {
+  if constexpr (M < 16) return row_xor<M>(x);
+  else return __shfl_xor(x, M, G);
+}
+// value held by lane J of the group, J a compile-time constant
+template <int G, int J> __device__ __forceinline__ double gbcast(double x) {
+  if constexpr (G == 16) return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + J, 0xf, 0xf, false);
+  else return __shfl(x, J, G);
+}
+// value of the lane D below / above (0 outside the group)
+template <int G, int D> __device__ __forceinline__ double gup(double x, int lane) {
+  if constexpr (G == 16) return dpp0<0x110 + D>(x);
+  else { double t = __shfl_up(x, D, G); return (lane >= D) ? t : 0.0; }
+}
+template <int G, int D> __device__ __forceinline__ double gdown(double x, int lane) {
+  if constexpr (G == 16) return dpp0<0x100 + D>(x);
+  else { double t = __shfl_down(x, D, G); return (lane + D < G) ? t : 0.0; }
+}
 
 template <int G> __device__ __forceinline__ double gsum(double x) {
-#pragma unroll
-  for (int m = 1; m < G; m <<= 1) x += gxor<G>(x, m);
+  x += gxor<G, 1>(x); x += gxor<G, 2>(x); x += gxor<G, 4>(x); x += gxor<G, 8>(x);
+  if constexpr (G == 32) x += gxor<G, 16>(x);
   return x;
 }
 template <int G> __device__ __forceinline__ double gmin(double x) {
-#pragma unroll
-  for (int m = 1; m < G; m <<= 1) x = fmin(x, gxor<G>(x, m));
+  x = fmin(x, gxor<G, 1>(x)); x = fmin(x, gxor<G, 2>(x)); x = fmin(x, gxor<G, 4>(x)); x = fmin(x, gxor<G, 8>(x));
+  if constexpr (G == 32) x = fmin(x, gxor<G, 16>(x));
   return x;
 }
 template <int G> __device__ __forceinline__ double gmax(double x) {
-#pragma unroll
-  for (int m = 1; m < G; m <<= 1) x = fmax(x, gxor<G>(x, m));
+  x = fmax(x, gxor<G, 1>(x)); x = fmax(x, gxor<G, 2>(x)); x = fmax(x, gxor<G, 4>(x)); x = fmax(x, gxor<G, 8>(x));
+  if constexpr (G == 32) x = fmax(x, gxor<G, 16>(x));
   return x;
 }
 // (value, index) arg-min with ties to the lower index (numpy argmin order on canonical rows)
+template <int G, int M> __device__ __forceinline__ void gargmin_step(double& v, int& i) {
+  const double ov = gxor<G, M>(v);
+  const int oi = gxor<G, M>(i);
+  const bool take = (ov < v) || (ov == v && oi < i);
+  v = take ? ov : v;
+  i = take ? oi : i;
+}
 template <int G> __device__ __forceinline__ void gargmin(double& v, int& i) {
-#pragma unroll
-  for (int m = 1; m < G; m <<= 1) {
-    double ov = gxor<G>(v, m);
-    int oi = __shfl_xor(i, m, G);
-    bool take = (ov < v) || (ov == v && oi < i);
-    v = take ? ov : v;
-    i = take ? oi : i;
-  }
+  gargmin_step<G, 1>(v, i); gargmin_step<G, 2>(v, i); gargmin_step<G, 4>(v, i); gargmin_step<G, 8>(v, i);
+  if constexpr (G == 32) gargmin_step<G, 16>(v, i);
 }
 // sums over earlier / later stages of the same coordinate (lane stride 2), exclusive
 template <int G> __device__ __forceinline__ double prefix_excl2(double v, int lane) {
   double s = v;
-#pragma unroll
-  for (int d = 2; d < G; d <<= 1) {
-    double t = gup<G>(s, d);
-    s += (lane >= d) ? t : 0.0;
-  }
+  s += gup<G, 2>(s, lane); s += gup<G, 4>(s, lane); s += gup<G, 8>(s, lane);
+  if constexpr (G == 32) s += gup<G, 16>(s, lane);
   return s - v;
 }
 template <int G> __device__ __forceinline__ double suffix_excl2(double v, int lane) {
   double s = v;
-#pragma unroll
-  for (int d = 2; d < G; d <<= 1) {
-    double t = gdown<G>(s, d);
-    s += (lane + d < G) ? t : 0.0;
-  }
+  s += gdown<G, 2>(s, lane); s += gdown<G, 4>(s, lane); s += gdown<G, 8>(s, lane);
+  if constexpr (G == 32) s += gdown<G, 16>(s, lane);
   return s - v;
+}
+// 1/sqrt(x), 1/x to working precision from the hardware seeds (v_rsq_f64 / v_rcp_f64) + Newton
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(fma(-x, y, 1.0), y, y);
+  y = fma(fma(-x, y, 1.0), y, y);
+  return y;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -285,14 +337,14 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
   // ---- linear row maps -------------------------------------------------------------------------
   // rows(x): lin[R_RU] = rr.(x_a - x_{a-1}); lin[R_VU] = wv.v_a(x); lin[R_CBF+t] = eta_t . x_a
   auto rows_lin = [&](double x, double& r_lin, double& w_lin, double (&h_lin)[NOBS_L > 0 ? NOBS_L : 1]) {
-    const double xp = gxor<G>(x, 1);
+    const double xp = gxor<G, 1>(x);
     const double xx = c ? xp : x, xy = c ? x : xp;
-    double pxx = gup<G>(xx, 2), pxy = gup<G>(xy, 2);
+    double pxx = gup<G, 2>(xx, lane), pxy = gup<G, 2>(xy, lane);
     if (a == 0) { pxx = 0.0; pxy = 0.0; }
     r_lin = rr0 * (xx - pxx) + rr1 * (xy - pxy);
     const double ps = prefix_excl2<G>(sgn_a * x, lane);
     const double vl = kap * x + 2.0 * kap * sgn_a * ps;
-    const double vlp = gxor<G>(vl, 1);
+    const double vlp = gxor<G, 1>(vl);
     const double vx = c ? vlp : vl, vy = c ? vl : vlp;
     w_lin = wv0 * vx + wv1 * vy;
 #pragma unroll
@@ -300,13 +352,13 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
   };
   // (G^T w)_lane from direction weights: tr (reach dir), tv (velocity dir), wc[t] (LDCBF rows, g = -eta)
   auto GT_apply = [&](double tr, double tv, const double (&wc)[NOBS_L > 0 ? NOBS_L : 1]) -> double {
-    const double trp = gxor<G>(tr, 1);
+    const double trp = gxor<G, 1>(tr);
     const double t0 = c ? trp : tr, t1 = c ? tr : trp;
     const double reach_own = c ? (sr * t0 + cr * t1) : (cr * t0 - sr * t1);
-    double reach_next = gdown<G>(reach_own, 2);
+    double reach_next = gdown<G, 2>(reach_own, lane);
     if (a + 1 >= N) reach_next = 0.0;
     double res = var_on ? (reach_own - reach_next) : 0.0;
-    const double tvp = gxor<G>(tv, 1);
+    const double tvp = gxor<G, 1>(tv);
     const double u0 = c ? tvp : tv, u1 = c ? tv : tvp;
     const double u = c ? (sv * u0 + cv * foot_v * u1) : (cv * u0 - sv * u1);
     const double uu = var_on ? u : 0.0;
@@ -315,22 +367,21 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
     double ax = 0.0, ay = 0.0;
 #pragma unroll
     for (int t = 0; t < NOBS_L; ++t) { ax += oex[t] * wc[t]; ay += oey[t] * wc[t]; }
-    const double recv = gxor<G>(c ? ax : ay, 1);
+    const double recv = gxor<G, 1>(c ? ax : ay);
     res -= (c ? ay : ax) + recv;
     return var_on ? res : 0.0;
   };
 
   // ---- K = 2I + G^T D G (lane = row), Cholesky, solves ----------------------------------------
   double Krow[NV];
-  double invd = 1.0;   // 1 / L[lane][lane]
   // dr = d_RU + d_RL, dv = d_VU + d_VL (+ d_M), dc[t] = LDCBF row weights
   auto form_K = [&](double dr, double dv, const double (&dc)[NOBS_L > 0 ? NOBS_L : 1]) {
-    const double drp = gxor<G>(dr, 1);
+    const double drp = gxor<G, 1>(dr);
     const double d0 = c ? drp : dr, d1 = c ? dr : drp;
     // F = Rr^T diag(d0,d1) Rr, Rr = [[cr,sr],[-sr,cr]]; this lane keeps row c
     const double F00 = cr * cr * d0 + sr * sr * d1, F01 = cr * sr * (d0 - d1), F11 = sr * sr * d0 + cr * cr * d1;
     const double Fc0 = c ? F01 : F00, Fc1 = c ? F11 : F01;
-    const double dvp = gxor<G>(dv, 1);
+    const double dvp = gxor<G, 1>(dv);
     const double e0 = c ? dvp : dv, e1 = c ? dv : dvp;
     // E = Wv^T diag(e0,e1) Wv, Wv = [[cv,sv],[-sv,cv*s]]
     const double E00 = cv * cv * e0 + sv * sv * e1, E01 = cv * sv * e0 - sv * cv * foot_v * e1, E11 = sv * sv * e0 + cv * cv * e1;
@@ -343,9 +394,9 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
     double cxx = 0.0, cxy = 0.0, cyy = 0.0;
 #pragma unroll
     for (int t = 0; t < NOBS_L; ++t) { cxx += dc[t] * oex[t] * oex[t]; cxy += dc[t] * oex[t] * oey[t]; cyy += dc[t] * oey[t] * oey[t]; }
-    cxx += gxor<G>(cxx, 1); cxy += gxor<G>(cxy, 1); cyy += gxor<G>(cyy, 1);
+    cxx += gxor<G, 1>(cxx); cxy += gxor<G, 1>(cxy); cyy += gxor<G, 1>(cyy);
     const double Cc0 = c ? cxy : cxx, Cc1 = c ? cyy : cxy;
-    double Fn0 = gdown<G>(Fc0, 2), Fn1 = gdown<G>(Fc1, 2);       // F_{a+1}, row c
+    double Fn0 = gdown<G, 2>(Fc0, lane), Fn1 = gdown<G, 2>(Fc1, lane);       // F_{a+1}, row c
     if (a + 1 >= N) { Fn0 = 0.0; Fn1 = 0.0; }
     __syncthreads();
 #pragma unroll
@@ -365,44 +416,45 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
     }
     __syncthreads();
   };
-  // right-looking Cholesky, full symmetric storage: afterwards Krow[j] = L[lane][j] (j <= lane)
-  // and L[j][lane] (j > lane).  Returns false on a non-positive pivot.
+  // Square-root-free right-looking factorisation K = Lt D^-1 Lt^T in full symmetric storage, one
+  // row per lane, nothing rescaled: after step j lane j keeps row j of the Schur complement
+  // (= column j of Lt, by symmetry) and lanes l > j keep Lt[l][j] in Krow[j]; ipiv = 1/pivot.
+  // Per (j, c) that is one row_newbcast move and one FMA, with f = 0 on lanes <= j instead of
+  // predication.  Returns false on a non-positive pivot.
+  double ipiv = 0.5;
   auto factor = [&]() -> bool {
     bool ok = true;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const double pj = gshfl<G>(Krow[j], j);
+    static_for<0, NV>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const double pj = gbcast<G, j>(Krow[j]);
       ok = ok && (pj > 0.0);
-      const double is = 1.0 / sqrt(pj);
-      const double lij = Krow[j] * is;
-#pragma unroll
-      for (int cc = j + 1; cc < NV; ++cc) {
-        const double lcj = gshfl<G>(Krow[cc], j) * is;
-        if (lane > j) Krow[cc] = fma(-lij, lcj, Krow[cc]);
-        else if (lane == j) Krow[cc] = lcj;                // column j of L lives on lane j
-      }
-      if (lane >= j) Krow[j] = lij;
-      if (lane == j) invd = is;     // 1/L[j][j] = 1/sqrt(pj)
-    }
+      const double ip = fast_rcp(pj);
+      const double f = (lane > j) ? Krow[j] * ip : 0.0;
+      if (lane == j) ipiv = ip;
+      static_for<j + 1, NV>([&](auto cc_) {
+        constexpr int cc = decltype(cc_)::value;
+        Krow[cc] = fma(-f, gbcast<G, j>(Krow[cc]), Krow[cc]);
+      });
+    });
     return ok;
   };
   auto solve = [&](double b) -> double {
-    // forward L y = b
-    double y = 0.0;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const double yj = gshfl<G>(b * invd, j);
-      if (lane == j) y = yj;
-      if (lane > j) b = fma(-Krow[j], yj, b);
-    }
-    // backward L^T x = y
-    double x = 0.0;
-#pragma unroll
-    for (int j = NV - 1; j >= 0; --j) {
-      const double xj = gshfl<G>(y * invd, j);
-      if (lane == j) x = xj;
-      if (lane < j) y = fma(-Krow[j], xj, y);
-    }
+    // forward Lt w = b: w_j = b_j / p_j, b_l -= Lt[l][j] w_j (l > j)
+    double w = 0.0;
+    static_for<0, NV>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const double wj = gbcast<G, j>(b * ipiv);
+      w = (lane == j) ? wj : w;
+      b = fma((lane > j) ? -Krow[j] : 0.0, wj, b);
+    });
+    // backward Lt^T x = D w: x_j = w_j - (1/p_j) sum_{l>j} Lt[l][j] x_l, lane j holds Lt[l][j] in Krow[l]
+    double acc = 0.0, x = 0.0;
+    static_rfor<NV, 0>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const double xj = gbcast<G, j>(fma(-ipiv, acc, w));
+      x = (lane == j) ? xj : x;
+      acc = fma((lane < j) ? Krow[j] : 0.0, xj, acc);
+    });
     return x;
   };
 
@@ -455,85 +507,98 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
   else if (front_flag & 1) { status = LIPMPC_STATUS_INFEASIBLE; done = true; }
   if (m_rows == 0.0 && !done) { status = LIPMPC_STATUS_SOLVED; done = true; q = var_on ? gc : 0.0; }
 
+  // row-presence masks as 0/1 doubles: an absent row keeps s = 1, z = 0 and is neutralised by four
+  // multiplies per iteration instead of predicated selects everywhere
+  double pm[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) pm[i] = pres[i] ? 1.0 : 0.0;
+
+  // Groups of a wave leave the loop independently (real divergence: a finished group's lanes are
+  // simply masked off; all exchanges inside are row-local DPP / group-local LDS).
   for (int it = 0; it <= P.max_iter; ++it) {
     if (__all(done)) break;
-    double rp[NR], w[NR], d[NR];
-    slack_values(q);
-    double mu_l = 0.0, rpmax_l = 0.0, zmax_l = 0.0;
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      rp[i] = pres[i] ? (s[i] - slk[i]) : 0.0;
-      mu_l += pres[i] ? s[i] * z[i] : 0.0;
-      rpmax_l = fmax(rpmax_l, fabs(rp[i]));
-      zmax_l = fmax(zmax_l, z[i]);
-    }
-    const double mu = gsum<G>(mu_l) / m_rows;
-    const double rpmax = gmax<G>(rpmax_l);
-    const double zmax = gmax<G>(zmax_l);
-    const bool bad = !(zmax < IPM_Z_DIVERGE) || !(gmax<G>(fabs(q)) < 1e300);
     if (!done) {
+      double rp[NR], w[NR], d[NR];
+      slack_values(q);
+      double mu_l = 0.0, rpmax_l = 0.0, zmax_l = 0.0;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        rp[i] = (s[i] - slk[i]) * pm[i];
+        mu_l = fma(s[i], z[i], mu_l);
+        rpmax_l = fmax(rpmax_l, fabs(rp[i]));
+        zmax_l = fmax(zmax_l, z[i]);
+      }
+      const double mu = gsum<G>(mu_l) / m_rows;
+      const double rpmax = gmax<G>(rpmax_l);
+      const double zmax = gmax<G>(zmax_l);
+      const bool bad = !(zmax < IPM_Z_DIVERGE) || !(gmax<G>(fabs(q)) < 1e300);
       if (rpmax <= P.tol && mu <= P.tol) { status = LIPMPC_STATUS_SOLVED; done = true; iters = it; }
       else if (it == P.max_iter) { done = true; iters = it; }
       else if (bad) { status = LIPMPC_STATUS_INFEASIBLE; done = true; iters = it; }
-    }
-    if (__all(done)) break;
-    // finished groups keep running with frozen state (step length 0) until the wave is done
+      if (!done) {
+        // Reciprocals once per row and iteration; every later division becomes a multiply, and the
+        // ratio tests run on -ds/s, -dz/z (largest ratio r => step 1/r) so they need no division.
+        double is_[NR], iz_[NR];
 #pragma unroll
-    for (int i = 0; i < NR; ++i) d[i] = pres[i] ? z[i] / s[i] : 0.0;
-    K_rows(d);
-    const bool fok = factor();
-    if (!fok && !done) {
-      // K loses numerical definiteness once max(z/s) ~ 1e15: near the solution that is
-      // "converged to working precision" (the finish takes over), elsewhere infeasibility
-      status = (rpmax <= IPM_STALL_TOL && mu <= IPM_STALL_TOL) ? LIPMPC_STATUS_SOLVED : LIPMPC_STATUS_INFEASIBLE;
-      done = true; iters = it;
-    }
-    const double gtz = GT_rows(z);
-    const double rd = var_on ? (2.0 * (q - gc) + gtz) : 0.0;
-    // predictor: rc = s z
+        for (int i = 0; i < NR; ++i) {
+          is_[i] = fast_rcp(s[i]);
+          iz_[i] = fast_rcp(fmax(z[i], 1e-300));
+          d[i] = z[i] * is_[i];
+        }
+        K_rows(d);
+        const bool fok = factor();
+        if (!fok) {
+          // K loses numerical definiteness once max(z/s) ~ 1e15: near the solution that is
+          // "converged to working precision" (the finish takes over), elsewhere infeasibility
+          status = (rpmax <= IPM_STALL_TOL && mu <= IPM_STALL_TOL) ? LIPMPC_STATUS_SOLVED : LIPMPC_STATUS_INFEASIBLE;
+          done = true; iters = it;
+        }
+        const double gtz = GT_rows(z);
+        const double rd = var_on ? (2.0 * (q - gc) + gtz) : 0.0;
+        // predictor: rc = s z  ->  w = z (rp - s) / s
 #pragma unroll
-    for (int i = 0; i < NR; ++i) w[i] = pres[i] ? (z[i] * rp[i] - s[i] * z[i]) / s[i] : 0.0;
-    double dq = solve(-rd - GT_rows(w));
-    double dl[NR], dsa[NR], dza[NR];
-    rows_dir(dq, dl);
-    double a_l = 1.0;
+        for (int i = 0; i < NR; ++i) w[i] = d[i] * (rp[i] - s[i]);
+        double dq = solve(-rd - GT_rows(w));
+        double dl[NR], dsa[NR], dza[NR];
+        rows_dir(dq, dl);
+        double r_l = 1.0;                                  // largest of 1, -ds/s, -dz/z
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      dsa[i] = pres[i] ? (-rp[i] - dl[i]) : 0.0;
-      dza[i] = pres[i] ? -(s[i] * z[i] + z[i] * dsa[i]) / s[i] : 0.0;
-      if (dsa[i] < 0.0) a_l = fmin(a_l, -s[i] / dsa[i]);
-      if (dza[i] < 0.0) a_l = fmin(a_l, -z[i] / dza[i]);
-    }
-    const double a_aff = gmin<G>(a_l);
-    double mua_l = 0.0;
+        for (int i = 0; i < NR; ++i) {
+          dsa[i] = (-rp[i] - dl[i]) * pm[i];
+          dza[i] = -d[i] * (s[i] + dsa[i]);               // -(s z + z ds)/s
+          r_l = fmax(r_l, fmax(-dsa[i] * is_[i], -dza[i] * iz_[i]));
+        }
+        const double a_aff = 1.0 / gmax<G>(r_l);
+        double mua_l = 0.0;
 #pragma unroll
-    for (int i = 0; i < NR; ++i) mua_l += pres[i] ? (s[i] + a_aff * dsa[i]) * (z[i] + a_aff * dza[i]) : 0.0;
-    const double mu_aff = gsum<G>(mua_l) / m_rows;
-    const double ratio = mu_aff / mu;
-    const double sigma_mu = ratio * ratio * ratio * mu;
-    // corrector: rc = s z + ds_a dz_a - sigma mu
-    double rc[NR];
+        for (int i = 0; i < NR; ++i) mua_l = fma(fma(a_aff, dsa[i], s[i]), fma(a_aff, dza[i], z[i]), mua_l);
+        const double mu_aff = gsum<G>(mua_l) / m_rows;
+        const double ratio = mu_aff / mu;
+        const double sigma_mu = ratio * ratio * ratio * mu;
+        // corrector: rc = s z + ds_a dz_a - sigma mu
+        double rc[NR];
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      rc[i] = pres[i] ? (s[i] * z[i] + dsa[i] * dza[i] - sigma_mu) : 0.0;
-      w[i] = pres[i] ? (z[i] * rp[i] - rc[i]) / s[i] : 0.0;
-    }
-    dq = solve(-rd - GT_rows(w));
-    rows_dir(dq, dl);
-    a_l = 1.0 / IPM_STEP_FRAC;
-    double ds[NR], dz[NR];
+        for (int i = 0; i < NR; ++i) {
+          rc[i] = (fma(s[i], z[i], dsa[i] * dza[i]) - sigma_mu) * pm[i];
+          w[i] = (z[i] * rp[i] - rc[i]) * is_[i];
+        }
+        dq = solve(-rd - GT_rows(w));
+        rows_dir(dq, dl);
+        r_l = IPM_STEP_FRAC;                               // alpha = min(1, 0.995 / max ratio)
+        double ds[NR], dz[NR];
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      ds[i] = pres[i] ? (-rp[i] - dl[i]) : 0.0;
-      dz[i] = pres[i] ? -(rc[i] + z[i] * ds[i]) / s[i] : 0.0;
-      if (ds[i] < 0.0) a_l = fmin(a_l, -s[i] / ds[i]);
-      if (dz[i] < 0.0) a_l = fmin(a_l, -z[i] / dz[i]);
-    }
-    double alpha = fmin(1.0, IPM_STEP_FRAC * gmin<G>(a_l));
-    if (!done) q = fma(alpha, dq, q);      // (a finished group's dq may be non-finite: never touch its q)
+        for (int i = 0; i < NR; ++i) {
+          ds[i] = (-rp[i] - dl[i]) * pm[i];
+          dz[i] = -fma(z[i], ds[i], rc[i]) * is_[i];
+          r_l = fmax(r_l, fmax(-ds[i] * is_[i], -dz[i] * iz_[i]));
+        }
+        const double alpha = IPM_STEP_FRAC / gmax<G>(r_l);
+        if (!done) {
+          q = fma(alpha, dq, q);
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      if (pres[i] && !done) { s[i] = fma(alpha, ds[i], s[i]); z[i] = fma(alpha, dz[i], z[i]); }
+          for (int i = 0; i < NR; ++i) { s[i] = fma(alpha, ds[i], s[i]); z[i] = fma(alpha, dz[i], z[i]); }
+        }
+      }
     }
   }
 
@@ -650,7 +715,7 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
   // velocities v_{a+1} of the solution
   const double ps = prefix_excl2<G>(sgn_a * q, lane);
   const double vsol = kap * q + 2.0 * kap * sgn_a * ps - sgn_a * (v0c + kap * p0c);
-  double pprev = gup<G>(q, 2), vprev = gup<G>(vsol, 2);
+  double pprev = gup<G, 2>(q, lane), vprev = gup<G, 2>(vsol, lane);
   if (a == 0) { pprev = p0c; vprev = v0c; }
   const double u = (q - P.ch * pprev - P.sh_over_beta * vprev) * P.inv_one_minus_ch;
   const double dg = var_on ? (q - gc) : 0.0;
