@@ -89,9 +89,12 @@ def synthetic_fields(B, n_obs, lo, hi, start, goal, seed, delta=1.0, v_max=5):
 
 
 def walk_states(solver_interior, obs_xy, obs_nv, goal, max_steps, seed, delta=None):
-    """Closed-loop warm-up on the device: every problem starts at rest in the origin, right foot
-    first, and keeps the state reached after w_b ~ U{0..max_steps} solved steps.  Returns
-    (state [B,5], first_foot [B] int8) device tensors."""
+    """Closed-loop warm-up on the device: every robot starts at rest in the origin, right foot
+    first, and walks w_b ~ U{0..max_steps} MPC steps; its benchmark state is the state it is in at
+    step w_b.  A robot whose loop has already stopped (the reference breaks out of run_simulation
+    on a failed solve, HumanoidMpc.py:419-429) contributes the last state from which its step was
+    still solvable, i.e. the batch holds live robots only.  Returns (state [B,5], first_foot [B]
+    int8) device tensors."""
     dev = solver_interior.device
     B = obs_xy.shape[0]
     gen = torch.Generator(device="cpu").manual_seed(seed)
@@ -100,10 +103,11 @@ def walk_states(solver_interior, obs_xy, obs_nv, goal, max_steps, seed, delta=No
     foot = torch.ones((B,), dtype=torch.int8, device=dev)
     keep_state, keep_foot = state.clone(), foot.clone()
     out = solver_interior.alloc_outputs(B)
-    for k in range(max_steps):
+    for k in range(max_steps + 1):
         solver_interior.plan_step_batch(state, goal, foot, obs_xy, obs_nv, delta, out=out)
-        solver_interior.advance(state, foot, out)
-        take = (w == k + 1)
+        ok = (out["status"] == 0) | (out["status"] == 4)
+        take = ok & (w >= k)                 # latest solvable state not beyond the robot's draw
         keep_state[take] = state[take]
         keep_foot[take] = foot[take]
+        solver_interior.advance(state, foot, out)
     return keep_state.contiguous(), keep_foot.contiguous()

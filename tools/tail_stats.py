@@ -36,3 +36,5 @@ easy=np.where((st==0)&(rounds<=1)&(it<=14))[0]; easy=easy[:len(easy)//4*4]
 timeit(easy,"status0, rounds<=1, iters<=14")
 timeit(np.repeat(ok[:1],4096),"4096 copies of one 12-iter problem" )
 print('iters of that problem', it[ok[0]], rounds[ok[0]])
+os.makedirs(os.path.join(ROOT,'gpurun_out'),exist_ok=True)
+np.savez_compressed(os.path.join(ROOT,'gpurun_out','bench_batch.npz'), state=state.cpu().numpy(), foot=foot.cpu().numpy(), goal=goal.cpu().numpy(), delta=delta.cpu().numpy(), obs_xy=xy, obs_nv=nv, status=r['status'], iters=r['iters'], diag=r['diag'], U=r['U'])
