@@ -74,13 +74,13 @@ template <int I, int E, class F> __device__ __forceinline__ void static_rfor(F&&
 }
 
 template <int CTRL, int BANK = 0xf, class T> __device__ __forceinline__ T dpp0(T x) {     // invalid source -> 0
-  return __builtin_amdgcn_update_dpp((T)0, x, CTRL, 0xf, BANK, true);
+  return __builtin_amdgcn_mov_dpp(x, CTRL, 0xf, BANK, true);        // no 'old' operand: no zero-init move
 }
 template <int M, class T> __device__ __forceinline__ T row_xor(T x) {
   if constexpr (M == 1) return dpp0<0xB1>(x);                 // quad_perm [1,0,3,2]
   else if constexpr (M == 2) return dpp0<0x4E>(x);            // quad_perm [2,3,0,1]
   else if constexpr (M == 4) {
-    T r = __builtin_amdgcn_update_dpp((T)0, x, 0x104, 0xf, 0x5, false);   // banks 0,2 <- lane+4
+    T r = __builtin_amdgcn_mov_dpp(x, 0x104, 0xf, 0x5, false);            // banks 0,2 <- lane+4
     return __builtin_amdgcn_update_dpp(r, x, 0x114, 0xf, 0xA, false);     // banks 1,3 <- lane-4
   } else return dpp0<0x128>(x);                               // row_ror:8
 }
@@ -90,7 +90,7 @@ template <int G, int M, class T> __device__ __forceinline__ T gxor(T x) {
 }
 // value held by lane J of the group, J a compile-time constant
 template <int G, int J> __device__ __forceinline__ double gbcast(double x) {
-  if constexpr (G == 16) return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + J, 0xf, 0xf, false);
+  if constexpr (G == 16) return __builtin_amdgcn_mov_dpp(x, 0x150 + J, 0xf, 0xf, false);
   else return __shfl(x, J, G);
 }
 // value of the lane D below / above (0 outside the group)
@@ -374,6 +374,9 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
 
   // ---- K = 2I + G^T D G (lane = row), Cholesky, solves ----------------------------------------
   double Krow[NV];
+  double eqm[NMAX];                      // eqm[b] = 1 if this lane's stage is b
+#pragma unroll
+  for (int b = 0; b < NMAX; ++b) eqm[b] = (b == a) ? 1.0 : 0.0;
   // dr = d_RU + d_RL, dv = d_VU + d_VL (+ d_M), dc[t] = LDCBF row weights
   auto form_K = [&](double dr, double dv, const double (&dc)[NOBS_L > 0 ? NOBS_L : 1]) {
     const double drp = gxor<G, 1>(dr);
@@ -396,23 +399,25 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
     for (int t = 0; t < NOBS_L; ++t) { cxx += dc[t] * oex[t] * oex[t]; cxy += dc[t] * oex[t] * oey[t]; cyy += dc[t] * oey[t] * oey[t]; }
     cxx += gxor<G, 1>(cxx); cxy += gxor<G, 1>(cxy); cyy += gxor<G, 1>(cyy);
     const double Cc0 = c ? cxy : cxx, Cc1 = c ? cyy : cxy;
-    double Fn0 = gdown<G, 2>(Fc0, lane), Fn1 = gdown<G, 2>(Fc1, lane);       // F_{a+1}, row c
-    if (a + 1 >= N) { Fn0 = 0.0; Fn1 = 0.0; }
+    // F_{a+1}, row c (0 past the last stage: lanes without rows have d = 0, hence F = 0)
+    const double Fn0 = gdown<G, 2>(Fc0, lane), Fn1 = gdown<G, 2>(Fc1, lane);
+    const double Dg0 = (c ? 0.0 : 2.0) - k2 * Ec0 + Fc0 + Fn0 + Cc0;
+    const double Dg1 = (c ? 2.0 : 0.0) - k2 * Ec1 + Fc1 + Fn1 + Cc1;
     __syncthreads();
+    // block b of the row: (-1)^(a+b) P_max(a,b) + [b==a] Dg - [b==a-1] F_a - [b==a+1] F_{a+1}; the three
+    // indicator terms are FMAs against 0/1 masks (eqm), not selects.  Lanes/stages beyond N fall
+    // out as rows of 2I because all their weights are zero.
 #pragma unroll
     for (int b = 0; b < NMAX; ++b) {
-      double q0v, q1v;
-      if (b <= a) { q0v = Pc0; q1v = Pc1; } else { q0v = lds_P[grp][b][c][0]; q1v = lds_P[grp][b][c][1]; }
-      const double sg = ((a + b) & 1) ? -1.0 : 1.0;
-      double k0 = sg * q0v, k1 = sg * q1v;
-      if (b == a) {
-        k0 += (c ? 0.0 : 2.0) - k2 * Ec0 + Fc0 + Fn0 + Cc0;
-        k1 += (c ? 2.0 : 0.0) - k2 * Ec1 + Fc1 + Fn1 + Cc1;
-      } else if (b == a - 1) { k0 -= Fc0; k1 -= Fc1; }
-      else if (b == a + 1) { k0 -= Fn0; k1 -= Fn1; }
-      const bool on = var_on && (b < N);
-      Krow[2 * b] = on ? k0 : ((2 * b == lane) ? 2.0 : 0.0);
-      Krow[2 * b + 1] = on ? k1 : ((2 * b + 1 == lane) ? 2.0 : 0.0);
+      const bool own = (b <= a);
+      const double q0v = own ? Pc0 : lds_P[grp][b][c][0];
+      const double q1v = own ? Pc1 : lds_P[grp][b][c][1];
+      const double sg = sgn_a * ((b & 1) ? -1.0 : 1.0);
+      double k0 = fma(eqm[b], Dg0, sg * q0v), k1 = fma(eqm[b], Dg1, sg * q1v);
+      if (b + 1 < NMAX) { k0 = fma(-eqm[b + 1], Fc0, k0); k1 = fma(-eqm[b + 1], Fc1, k1); }
+      if (b >= 1) { k0 = fma(-eqm[b - 1], Fn0, k0); k1 = fma(-eqm[b - 1], Fn1, k1); }
+      Krow[2 * b] = k0;
+      Krow[2 * b + 1] = k1;
     }
     __syncthreads();
   };
@@ -439,23 +444,22 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
     return ok;
   };
   auto solve = [&](double b) -> double {
-    // forward Lt w = b: w_j = b_j / p_j, b_l -= Lt[l][j] w_j (l > j)
-    double w = 0.0;
+    // forward Lt w = b: w_j = b_j / p_j, b_l -= Lt[l][j] w_j (l > j); lane j's b is final after step j
     static_for<0, NV>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       const double wj = gbcast<G, j>(b * ipiv);
-      w = (lane == j) ? wj : w;
       b = fma((lane > j) ? -Krow[j] : 0.0, wj, b);
     });
-    // backward Lt^T x = D w: x_j = w_j - (1/p_j) sum_{l>j} Lt[l][j] x_l, lane j holds Lt[l][j] in Krow[l]
-    double acc = 0.0, x = 0.0;
+    const double w = b * ipiv;
+    // backward Lt^T x = D w: x_j = w_j - (1/p_j) sum_{l>j} Lt[l][j] x_l, lane j holds Lt[l][j] in Krow[l];
+    // lane j's acc is final once step j+1 is done
+    double acc = 0.0;
     static_rfor<NV, 0>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       const double xj = gbcast<G, j>(fma(-ipiv, acc, w));
-      x = (lane == j) ? xj : x;
       acc = fma((lane < j) ? Krow[j] : 0.0, xj, acc);
     });
-    return x;
+    return fma(-ipiv, acc, w);
   };
 
   // ---- interior point ---------------------------------------------------------------------------
