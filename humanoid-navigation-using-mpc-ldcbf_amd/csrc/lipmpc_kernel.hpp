@@ -150,11 +150,10 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
   y = y * fma(-0.5 * x * y, y, 1.5);
   return y;
 }
+// v_rcp_f64 is accurate to 4.5e-8 (measured, tools/rcp_test.hip); one Newton step gives 2e-15
 __device__ __forceinline__ double fast_rcp(double x) {
   double y = __builtin_amdgcn_rcp(x);
-  y = fma(fma(-x, y, 1.0), y, y);
-  y = fma(fma(-x, y, 1.0), y, y);
-  return y;
+  return fma(fma(-x, y, 1.0), y, y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -523,7 +522,6 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
     if (__all(done)) break;
     if (!done) {
       double rp[NR], w[NR], d[NR];
-      slack_values(q);
       double mu_l = 0.0, rpmax_l = 0.0, zmax_l = 0.0;
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
@@ -534,19 +532,20 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
       }
       const double mu = gsum<G>(mu_l) / m_rows;
       const double rpmax = gmax<G>(rpmax_l);
-      const double zmax = gmax<G>(zmax_l);
-      const bool bad = !(zmax < IPM_Z_DIVERGE) || !(gmax<G>(fabs(q)) < 1e300);
+      const double zq = gmax<G>(fmax(zmax_l * (1.0 / IPM_Z_DIVERGE), fabs(q) * 1e-300));   // >= 1: diverged
+      const bool bad = !(zq < 1.0);
       if (rpmax <= P.tol && mu <= P.tol) { status = LIPMPC_STATUS_SOLVED; done = true; iters = it; }
       else if (it == P.max_iter) { done = true; iters = it; }
       else if (bad) { status = LIPMPC_STATUS_INFEASIBLE; done = true; iters = it; }
       if (!done) {
         // Reciprocals once per row and iteration; every later division becomes a multiply, and the
         // ratio tests run on -ds/s, -dz/z (largest ratio r => step 1/r) so they need no division.
+        // 1/z only feeds a ratio test: the 4.5e-8-accurate hardware seed is enough there.
         double is_[NR], iz_[NR];
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
           is_[i] = fast_rcp(s[i]);
-          iz_[i] = fast_rcp(fmax(z[i], 1e-300));
+          iz_[i] = __builtin_amdgcn_rcp(fmax(z[i], 1e-300));
           d[i] = z[i] * is_[i];
         }
         K_rows(d);
@@ -557,12 +556,12 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
           status = (rpmax <= IPM_STALL_TOL && mu <= IPM_STALL_TOL) ? LIPMPC_STATUS_SOLVED : LIPMPC_STATUS_INFEASIBLE;
           done = true; iters = it;
         }
-        const double gtz = GT_rows(z);
-        const double rd = var_on ? (2.0 * (q - gc) + gtz) : 0.0;
+        // right-hand sides  -r_d - G^T w = -2(q - g) - G^T (z + w): one transpose apply per solve.
         // predictor: rc = s z  ->  w = z (rp - s) / s
+        const double m2qg = var_on ? -2.0 * (q - gc) : 0.0;
 #pragma unroll
-        for (int i = 0; i < NR; ++i) w[i] = d[i] * (rp[i] - s[i]);
-        double dq = solve(-rd - GT_rows(w));
+        for (int i = 0; i < NR; ++i) w[i] = fma(d[i], rp[i] - s[i], z[i]);
+        double dq = solve(m2qg - GT_rows(w));
         double dl[NR], dsa[NR], dza[NR];
         rows_dir(dq, dl);
         double r_l = 1.0;                                  // largest of 1, -ds/s, -dz/z
@@ -584,9 +583,9 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
           rc[i] = (fma(s[i], z[i], dsa[i] * dza[i]) - sigma_mu) * pm[i];
-          w[i] = (z[i] * rp[i] - rc[i]) * is_[i];
+          w[i] = fma(fma(z[i], rp[i], -rc[i]), is_[i], z[i]);
         }
-        dq = solve(-rd - GT_rows(w));
+        dq = solve(m2qg - GT_rows(w));
         rows_dir(dq, dl);
         r_l = IPM_STEP_FRAC;                               // alpha = min(1, 0.995 / max ratio)
         double ds[NR], dz[NR];
@@ -599,8 +598,11 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
         const double alpha = IPM_STEP_FRAC / gmax<G>(r_l);
         if (!done) {
           q = fma(alpha, dq, q);
+          // slack functions are affine in q: h - g.(q + a dq) = slk - a g.dq (recomputed from q in the finish)
 #pragma unroll
-          for (int i = 0; i < NR; ++i) { s[i] = fma(alpha, ds[i], s[i]); z[i] = fma(alpha, dz[i], z[i]); }
+          for (int i = 0; i < NR; ++i) {
+            s[i] = fma(alpha, ds[i], s[i]); z[i] = fma(alpha, dz[i], z[i]); slk[i] = fma(-alpha, dl[i], slk[i]);
+          }
         }
       }
     }
