@@ -40,7 +40,8 @@ constexpr double IPM_Z_DIVERGE = 1e13;
 constexpr double IPM_STALL_TOL = 1e-6;   // Cholesky breakdown below this (r_p, mu) counts as converged
 constexpr double FIN_RHO = 1e10;
 constexpr double FIN_EPS = 1e-9;
-constexpr int FIN_ROUNDS = 8;
+constexpr int FIN_ROUNDS = 10;
+constexpr double FIN_IDENT = 1e5;   // initial working set z > FIN_IDENT * s: a deliberate under-estimate (oracle docstring)
 constexpr int FIN_INNER = 6;
 constexpr double FIN_INNER_TOL = 1e-11;
 
@@ -612,7 +613,7 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
   double marg_l = INFINITY, mufin_l = 0.0;
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
-    if (pres[i]) { marg_l = fmin(marg_l, fabs(log(z[i] / s[i]))); mufin_l += s[i] * z[i]; }
+    if (pres[i]) { marg_l = fmin(marg_l, fabs(log(z[i] / (FIN_IDENT * s[i])))); mufin_l += s[i] * z[i]; }
   }
   const double margin = gmin<G>(marg_l);
   const double mu_fin = gsum<G>(mufin_l) / fmax(m_rows, 1.0);
@@ -621,7 +622,7 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
   // ---- certified active-set finish --------------------------------------------------------------
   bool act[NR];
 #pragma unroll
-  for (int i = 0; i < NR; ++i) act[i] = pres[i] && (z[i] > s[i]);
+  for (int i = 0; i < NR; ++i) act[i] = pres[i] && (z[i] > FIN_IDENT * s[i]);
   const bool ipm_ok = (status == LIPMPC_STATUS_SOLVED) && (m_rows > 0.0);
   if (!(P.flags & LIPMPC_FLAG_INTERIOR)) {
     bool fin_done = !ipm_ok;        // groups that never converged skip the finish
@@ -711,7 +712,7 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
       } else {
         status = LIPMPC_STATUS_UNCERTIFIED;
 #pragma unroll
-        for (int i = 0; i < NR; ++i) act[i] = pres[i] && (z[i] > s[i]);
+        for (int i = 0; i < NR; ++i) act[i] = pres[i] && (z[i] > FIN_IDENT * s[i]);
       }
     }
   }

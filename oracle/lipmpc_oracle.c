@@ -35,8 +35,8 @@
 
 static const double IPM_S_FLOOR = 0.1, IPM_Z0 = 30.0, IPM_STEP_FRAC = 0.995, IPM_Z_DIVERGE = 1e13;
 static const double IPM_STALL_TOL = 1e-6;
-static const double FIN_RHO = 1e10, FIN_EPS = 1e-9, FIN_INNER_TOL = 1e-11;
-enum { FIN_ROUNDS = 8, FIN_INNER = 6 };
+static const double FIN_RHO = 1e10, FIN_EPS = 1e-9, FIN_INNER_TOL = 1e-11, FIN_IDENT = 1e5;
+enum { FIN_ROUNDS = 10, FIN_INNER = 6 };
 
 /* ---- geometry (ObstaclesUtils.py:50-109) ------------------------------------------------ */
 static void closest_point_normal(const double* ring, int nv, double px, double py, double* cx, double* cy,
@@ -325,13 +325,13 @@ static void plan_one(const lipmpc_params* P, work_t* W, const double* st, const 
   *status_out = status;
   if (status != LIPMPC_STATUS_SOLVED) return;
   double margin = INFINITY;
-  for (int i = 0; i < m; ++i) margin = fmin(margin, fabs(log(z[i] / s[i])));
+  for (int i = 0; i < m; ++i) margin = fmin(margin, fabs(log(z[i] / (FIN_IDENT * s[i]))));
   if (diag) { diag[2] = margin; diag[3] = mu; }
 
   /* ---- certified active-set finish ------------------------------------------------------------- */
   int* act = W->act;
   double* y = W->y; double* slack = W->slack;
-  for (int i = 0; i < m; ++i) act[i] = z[i] > s[i];
+  for (int i = 0; i < m; ++i) act[i] = z[i] > FIN_IDENT * s[i];   /* under-estimate: see lipmpc_oracle.py */
   if (!(P->flags & LIPMPC_FLAG_INTERIOR)) {
     double qf[NMAXV];
     memcpy(qf, q, sizeof(double) * n);
@@ -377,7 +377,7 @@ static void plan_one(const lipmpc_params* P, work_t* W, const double* st, const 
     }
     if (diag) { diag[0] = rounds; diag[1] = eres; }
     if (certified) memcpy(q, qf, sizeof(double) * n);
-    else { status = LIPMPC_STATUS_UNCERTIFIED; for (int i = 0; i < m; ++i) act[i] = z[i] > s[i]; }
+    else { status = LIPMPC_STATUS_UNCERTIFIED; for (int i = 0; i < m; ++i) act[i] = z[i] > FIN_IDENT * s[i]; }
   }
   *status_out = status;
   for (int i = 0; i < m; ++i)

@@ -340,7 +340,8 @@ IPM_Z_DIVERGE = 1e13   # multiplier blow-up => infeasible
 IPM_STALL_TOL = 1e-6   # Cholesky breakdown below this (r_p, mu) counts as converged
 FIN_RHO = 1e10         # penalty of the active-set equality solve
 FIN_EPS = 1e-9         # sign / violation threshold of the certificate
-FIN_ROUNDS = 8         # max add/drop rounds
+FIN_ROUNDS = 10        # max add/drop rounds
+FIN_IDENT = 1e5        # initial working set: z_i > FIN_IDENT * s_i (see finish_active_set)
 FIN_INNER = 6          # max multiplier iterations per equality solve
 FIN_INNER_TOL = 1e-11
 
@@ -440,14 +441,18 @@ def eqp_multiplier_method(G, h, g, active, q, y_full):
 
 def finish_active_set(G, h, g, res: QPResult):
     """Turn the interior-point estimate into the exact minimiser with a KKT certificate.
-    Working set A <- {i : z_i > s_i}; solve the equality-constrained problem on A; if some
+    Working set A <- {i : z_i > 1e5 s_i}; solve the equality-constrained problem on A; if some
     multiplier is < -1e-9 drop the most negative one, else if some row outside A is violated
-    by more than 1e-9 add the most violated one; repeat (<= 8 rounds).  When neither happens
+    by more than 1e-9 add the most violated one; repeat (<= 10 rounds).  The initial set is a
+    deliberate UNDER-estimate (only rows with a substantial multiplier): a missing row shows up
+    as an unambiguous violation and is added in one round, whereas a wrongly included, nearly
+    degenerate row (the CoM sliding along one obstacle's half-plane over several stages) makes
+    the multipliers of the equality solve non-unique and their signs unreliable.  When neither happens
     (and the equality solve converged to 1e-9) the point satisfies primal feasibility, dual
     feasibility and complementarity, i.e. it is the unique optimum of the strictly convex QP."""
     m = G.shape[0]
     nz = np.any(G != 0.0, axis=1)
-    A = (res.z > res.s) & nz
+    A = (res.z > FIN_IDENT * res.s) & nz
     q, yf = res.q, np.where(A, res.z, 0.0)
     for rnd in range(1, FIN_ROUNDS + 1):
         q, y, eres = eqp_multiplier_method(G, h, g, A, q, yf)
@@ -477,7 +482,7 @@ def solve_qp_exact(G, h, g, q0, tol=1e-9, max_iter=60):
         return res
     nz = np.any(G != 0.0, axis=1)
     with np.errstate(divide="ignore"):
-        lr = np.abs(np.log(res.z[nz] / res.s[nz]))
+        lr = np.abs(np.log(res.z[nz] / (FIN_IDENT * res.s[nz])))
     res.margin = float(np.min(lr)) if lr.size else math.inf
     q, y, slack, A, rounds, ok = finish_active_set(G, h, g, res)
     res.rounds = rounds
@@ -485,7 +490,7 @@ def solve_qp_exact(G, h, g, q0, tol=1e-9, max_iter=60):
         res.q, res.z, res.s, res.active = q, y, np.maximum(slack, 0.0), A
     else:
         res.status = STATUS_UNCERTIFIED
-        res.active = (res.z > res.s) & nz
+        res.active = (res.z > FIN_IDENT * res.s) & nz
     return res
 
 
