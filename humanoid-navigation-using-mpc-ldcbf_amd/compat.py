@@ -102,6 +102,38 @@ class HumanoidMPC:
     # -- the closed loop (HumanoidMpc.py:345-494) ------------------------------------------------
     def run_simulation(self, path_to_gif: str = None, make_fast_plot: bool = True, plot_animation: bool = False,
                        fill_animator: bool = True, initial_animator=None):
+        if type(self)._get_obstacle_rings is HumanoidMPC._get_obstacle_rings:
+            return self._run_on_device(initial_animator)       # static obstacles: whole loop in one launch
+        return self._run_stepwise(initial_animator)            # sensed / changing obstacles: one launch per sample
+
+    def _run_on_device(self, initial_animator):
+        rings = self._get_obstacle_rings(self.init_state[0], self.init_state[2])
+        n_obs = len(rings)
+        v_max = max([3] + [len(r) for r in rings])
+        if self._solver is None or self._solver.params.n_obs_max != n_obs or self._solver.params.v_max < v_max:
+            self._solver = self._make_solver(n_obs, v_max)
+        sv = self._solver
+        dev = sv.device
+        xy, nv = pack_rings([rings], n_obs, sv.params.v_max)
+        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+        out = sv.rollout(t(self.init_state[None, :], torch.float64), t(np.asarray(self.goal, float)[None, :], torch.float64),
+                         t(np.array([self.s_v[0]], np.int8), torch.int8),
+                         t(xy, torch.float64) if n_obs else None, t(nv, torch.int32) if n_obs else None,
+                         t(np.array([self.distance_from_obstacles], float), torch.float64),
+                         k_max=self.num_inputs, mpc_step=self.mpc_step)
+        torch.cuda.synchronize(dev)
+        n = int(out["n_steps"][0])
+        self.last_status = int(out["last_status"][0])
+        if self.last_status not in (STATUS_SOLVED, STATUS_UNCERTIFIED) and self.verbosity > 0:
+            print(f"===== ERROR ({n}) ===== solver status {self.last_status}")       # HumanoidMpc.py:419-429
+        X = out["X_pred"][0].cpu().numpy().T
+        U = out["U_pred"][0].cpu().numpy().T
+        # the reference's truncation X[:, :k+1], U[:, :k] with k the last loop index (:457-459): a run that
+        # uses every sample loses its final state and input, exactly as there
+        k = n if n < self.num_inputs else self.num_inputs - 1
+        return X[:, :k + 1].copy(), U[:, :k].copy(), initial_animator
+
+    def _run_stepwise(self, initial_animator):
         X_pred = np.zeros((5, self.num_inputs + 1))
         U_pred = np.zeros((3, self.num_inputs))
         X_pred[:, 0] = self.init_state

@@ -119,6 +119,40 @@ int lipmpc_plan_step_batch(lipmpc_handle* h, int64_t B, const double* state, con
   return hipGetLastError() == hipSuccess ? LIPMPC_OK : LIPMPC_E_HIP;
 }
 
+#define LAUNCH_RO(GG, NL)                                                                                        \
+  launch_rollout<GG, NL>(h->k, (long)B, k_max, mpc_step, stop_obj, state0, goal, first_foot, delta, obs_xy, obs_nv, \
+                         X_pred, U_pred, n_steps, last_status, total_iters, stream)
+
+int lipmpc_rollout_batch(lipmpc_handle* h, int64_t B, int32_t k_max, int32_t mpc_step, double stop_obj,
+                         const double* state0, const double* goal, const int8_t* first_foot, const double* delta,
+                         const double* obs_xy, const int32_t* obs_nv, double* X_pred, double* U_pred,
+                         int32_t* n_steps, int32_t* last_status, int32_t* total_iters, void* hip_stream) {
+  if (!h || B < 0 || k_max < 1 || mpc_step < 1) return LIPMPC_E_ARG;
+  if (B == 0) return LIPMPC_OK;
+  if (!state0 || !goal || !first_foot || !X_pred || !U_pred || !n_steps || !last_status || !total_iters) return LIPMPC_E_ARG;
+  if (h->p.n_obs_max > 0 && (!obs_xy || !obs_nv)) return LIPMPC_E_ARG;
+  if (hipSetDevice(h->device) != hipSuccess) return LIPMPC_E_HIP;
+  hipStream_t stream = (hipStream_t)hip_stream;
+  if (h->G == 16) {
+    switch (h->nobs_l) {
+      case 0: LAUNCH_RO(16, 0); break;
+      case 2: LAUNCH_RO(16, 2); break;
+      case 5: LAUNCH_RO(16, 5); break;
+      case 13: LAUNCH_RO(16, 13); break;
+      default: LAUNCH_RO(16, 25); break;
+    }
+  } else {
+    switch (h->nobs_l) {
+      case 0: LAUNCH_RO(32, 0); break;
+      case 2: LAUNCH_RO(32, 2); break;
+      case 5: LAUNCH_RO(32, 5); break;
+      case 13: LAUNCH_RO(32, 13); break;
+      default: LAUNCH_RO(32, 25); break;
+    }
+  }
+  return hipGetLastError() == hipSuccess ? LIPMPC_OK : LIPMPC_E_HIP;
+}
+
 int lipmpc_advance_batch(lipmpc_handle* h, int64_t B, double* state, int8_t* first_foot, const double* U,
                          const double* theta, const int32_t* status, void* hip_stream) {
   if (!h || B < 0) return LIPMPC_E_ARG;

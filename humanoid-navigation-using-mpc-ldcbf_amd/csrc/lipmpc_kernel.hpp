@@ -209,11 +209,21 @@ __device__ __noinline__ void closest_point_normal(const double* __restrict__ rin
 // local row slots of a lane
 constexpr int R_RU = 0, R_RL = 1, R_VU = 2, R_VL = 3, R_M = 4, R_CBF = 5;
 
+// one problem's inputs as the group sees them / what the closed loop needs back
+struct StepIn {
+  double p0x, v0x, p0y, v0y, th0, gx, gy, foot0, delta;
+  long pb;          // problem index (obstacle arrays, step outputs)
+  bool valid;       // false: padding group of the last workgroup (computes, never writes)
+};
+struct StepOut {
+  int status, iters;
+  double ux, uy, theta1, omega0, obj;   // first footstep, next heading, first turning rate, objective
+};
+
+// The whole MPC step of one problem on one group of G lanes.  Output pointers may be null.
 template <int G, int NOBS_L>
-__global__ __launch_bounds__(64) void plan_step_kernel(
-    KArgs P, long B, const double* __restrict__ state, const double* __restrict__ goal,
-    const int8_t* __restrict__ first_foot, const double* __restrict__ delta_in,
-    const double* __restrict__ obs_xy, const int32_t* __restrict__ obs_nv,
+__device__ __forceinline__ StepOut step_body(
+    const KArgs& P, const StepIn& in, const double* __restrict__ obs_xy, const int32_t* __restrict__ obs_nv,
     double* __restrict__ U, double* __restrict__ X, double* __restrict__ theta_out,
     double* __restrict__ omega_out, double* __restrict__ obj_out, int32_t* __restrict__ status_out,
     int32_t* __restrict__ iters_out, unsigned long long* __restrict__ active_out, double* __restrict__ c_eta,
@@ -233,9 +243,8 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & (G - 1);
   const int grp = tid / G;
-  const long prob_raw = (long)blockIdx.x * GPW + grp;
-  const bool valid = prob_raw < B;
-  const long pb = valid ? prob_raw : (B - 1);
+  const bool valid = in.valid;
+  const long pb = in.pb;
   const int N = P.N;
   const int a = lane >> 1;             // stage index: variable = p_{a+1}
   const int c = lane & 1;              // coordinate
@@ -243,26 +252,22 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
   const double sgn_a = (a & 1) ? -1.0 : 1.0;
   const double kap = P.kappa;
 
-  // ---- inputs (every lane of the group reads the same 64 B: one broadcast transaction) -------
-  const double p0x = state[pb * 5 + 0], v0x = state[pb * 5 + 1];
-  const double p0y = state[pb * 5 + 2], v0y = state[pb * 5 + 3];
-  const double th0 = state[pb * 5 + 4];
-  const double gx = goal[pb * 2 + 0], gy = goal[pb * 2 + 1];
-  const double foot0 = (double)first_foot[pb];
-  const double delta = delta_in ? delta_in[pb] : 0.0;
+  const double p0x = in.p0x, v0x = in.v0x, p0y = in.p0y, v0y = in.v0y, th0 = in.th0;
+  const double gx = in.gx, gy = in.gy, foot0 = in.foot0, delta = in.delta;
   const double p0c = c ? p0y : p0x, v0c = c ? v0y : v0x, gc = c ? gy : gx;
 
   // ---- theta / omega (HumanoidMpc.py:137-160) -------------------------------------------------
   const double psi = atan2(gy - p0y, gx - p0x);
-  double th_r = 0.0, th_v = 0.0, om_a = 0.0;
+  double th_r = 0.0, th_v = 0.0, om_a = 0.0, theta1 = th0, omega0 = 0.0;
   {
     double th = th0;
-    if (valid && lane == 0) theta_out[pb * (N + 1)] = th0;
+    if (valid && lane == 0 && theta_out) theta_out[pb * (N + 1)] = th0;
     for (int k = 0; k < N; ++k) {
       double w = fmin(fmax(psi - th, -P.omega_max), P.omega_max);
       double thn = th + w * P.tau;
       if (k == a) { th_r = th; th_v = thn; om_a = w; }
-      if (valid && lane == 0) { omega_out[pb * N + k] = w; theta_out[pb * (N + 1) + k + 1] = thn; }
+      if (k == 0) { theta1 = thn; omega0 = w; }
+      if (valid && lane == 0 && theta_out) { omega_out[pb * N + k] = w; theta_out[pb * (N + 1) + k + 1] = thn; }
       th = thn;
     }
   }
@@ -740,7 +745,7 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
     }
   }
   __syncthreads();
-  if (valid) {
+  if (valid && X) {
     const double nanv = NAN;
     if (var_on) {
       double* Xo = X + (pb * (N + 1) + a + 1) * 4;
@@ -761,8 +766,113 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
     }
     for (int wi = lane; wi < P.words; wi += G) active_out[pb * P.words + wi] = lds_act[grp][wi];
   }
+  StepOut r;
+  r.status = status; r.iters = iters; r.theta1 = theta1; r.omega0 = omega0; r.obj = objv;
+  r.ux = gbcast<G, 0>(u); r.uy = gbcast<G, 1>(u);
+  return r;
 }
 
+// ------------------------------------------------------------------------------------------
+// kernel 1: one MPC step for B problems (lipmpc_plan_step_batch)
+// ------------------------------------------------------------------------------------------
+template <int G, int NOBS_L>
+__global__ __launch_bounds__(64) void plan_step_kernel(
+    KArgs P, long B, const double* __restrict__ state, const double* __restrict__ goal,
+    const int8_t* __restrict__ first_foot, const double* __restrict__ delta_in,
+    const double* __restrict__ obs_xy, const int32_t* __restrict__ obs_nv,
+    double* __restrict__ U, double* __restrict__ X, double* __restrict__ theta_out,
+    double* __restrict__ omega_out, double* __restrict__ obj_out, int32_t* __restrict__ status_out,
+    int32_t* __restrict__ iters_out, unsigned long long* __restrict__ active_out, double* __restrict__ c_eta,
+    double* __restrict__ diag) {
+  constexpr int GPW = 64 / G;
+  const long prob_raw = (long)blockIdx.x * GPW + threadIdx.x / G;
+  StepIn in;
+  in.valid = prob_raw < B;
+  const long pb = in.valid ? prob_raw : (B - 1);
+  in.pb = pb;
+  // every lane of the group reads the same 64 B: one broadcast transaction
+  in.p0x = state[pb * 5 + 0]; in.v0x = state[pb * 5 + 1]; in.p0y = state[pb * 5 + 2]; in.v0y = state[pb * 5 + 3];
+  in.th0 = state[pb * 5 + 4];
+  in.gx = goal[pb * 2 + 0]; in.gy = goal[pb * 2 + 1];
+  in.foot0 = (double)first_foot[pb];
+  in.delta = delta_in ? delta_in[pb] : 0.0;
+  step_body<G, NOBS_L>(P, in, obs_xy, obs_nv, U, X, theta_out, omega_out, obj_out, status_out, iters_out, active_out,
+                       c_eta, diag);
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel 2: the closed loop of HumanoidMPC.run_simulation on the device (lipmpc_rollout_batch),
+// HumanoidMpc.py:380-459: per sample k: stop if the previous objective < 0.05 (:392); on MPC samples
+// (k % mpc_step == 0) solve the step, keep u_0 (:432), advance x+ = A x + B u_0 (:441-442); on the
+// other samples only the heading moves (:443-447); theta <- theta_1 (:447); the stance foot of MPC step
+// number floor(k / mpc_step) alternates (:104-108, 401-403).  A failed solve ends the robot's run (:419-429).
+// Each group owns one robot for the whole run: no host round trip, no batch-wide barrier per step.
+// ------------------------------------------------------------------------------------------
+template <int G, int NOBS_L>
+__global__ __launch_bounds__(64) void rollout_kernel(
+    KArgs P, long B, int k_max, int mpc_step, double stop_obj, const double* __restrict__ state0,
+    const double* __restrict__ goal, const int8_t* __restrict__ first_foot, const double* __restrict__ delta_in,
+    const double* __restrict__ obs_xy, const int32_t* __restrict__ obs_nv, double* __restrict__ X_pred,
+    double* __restrict__ U_pred, int32_t* __restrict__ n_steps, int32_t* __restrict__ last_status,
+    int32_t* __restrict__ total_iters) {
+  constexpr int GPW = 64 / G;
+  const int lane = threadIdx.x & (G - 1);
+  const long prob_raw = (long)blockIdx.x * GPW + threadIdx.x / G;
+  StepIn in;
+  in.valid = prob_raw < B;
+  const long pb = in.valid ? prob_raw : (B - 1);
+  in.pb = pb;
+  in.p0x = state0[pb * 5 + 0]; in.v0x = state0[pb * 5 + 1]; in.p0y = state0[pb * 5 + 2]; in.v0y = state0[pb * 5 + 3];
+  in.th0 = state0[pb * 5 + 4];
+  in.gx = goal[pb * 2 + 0]; in.gy = goal[pb * 2 + 1];
+  in.foot0 = (double)first_foot[pb];
+  in.delta = delta_in ? delta_in[pb] : 0.0;
+  double* Xp = X_pred + pb * (long)(k_max + 1) * 5;
+  double* Up = U_pred + pb * (long)k_max * 3;
+  if (in.valid && lane == 0) { Xp[0] = in.p0x; Xp[1] = in.v0x; Xp[2] = in.p0y; Xp[3] = in.v0y; Xp[4] = in.th0; }
+  bool fin = false;
+  int k_done = 0, st_last = LIPMPC_STATUS_SOLVED, it_sum = 0;
+  double last_obj = INFINITY, ukx = 0.0, uky = 0.0;
+  for (int k = 0; k < k_max; ++k) {
+    if (!fin && last_obj < stop_obj) fin = true;
+    if (__all(fin)) break;
+    if (!fin) {
+      const bool is_mpc = (k % mpc_step) == 0;
+      double theta1, omega0;
+      if (is_mpc) {     // group-uniform (k and mpc_step are wave-uniform)
+        const StepOut r = step_body<G, NOBS_L>(P, in, obs_xy, obs_nv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                               nullptr, nullptr, nullptr, nullptr);
+        st_last = r.status;
+        it_sum += r.iters;
+        theta1 = r.theta1; omega0 = r.omega0;
+        if (r.status != LIPMPC_STATUS_SOLVED && r.status != LIPMPC_STATUS_UNCERTIFIED) fin = true;
+        else { last_obj = r.obj; ukx = r.ux; uky = r.uy; }
+      } else {
+        const double psi = atan2(in.gy - in.p0y, in.gx - in.p0x);
+        omega0 = fmin(fmax(psi - in.th0, -P.omega_max), P.omega_max);
+        theta1 = in.th0 + omega0 * P.tau;
+      }
+      if (!fin) {
+        if (is_mpc) {
+          const double px = in.p0x, vx = in.v0x, py = in.p0y, vy = in.v0y;
+          in.p0x = P.ch * px + P.sh_over_beta * vx + (1.0 - P.ch) * ukx;
+          in.v0x = P.beta_sh * px + P.ch * vx - P.beta_sh * ukx;
+          in.p0y = P.ch * py + P.sh_over_beta * vy + (1.0 - P.ch) * uky;
+          in.v0y = P.beta_sh * py + P.ch * vy - P.beta_sh * uky;
+        }
+        in.th0 = theta1;
+        if ((k + 1) % mpc_step == 0) in.foot0 = -in.foot0;
+        if (in.valid && lane == 0) {
+          Up[3 * k] = ukx; Up[3 * k + 1] = uky; Up[3 * k + 2] = omega0;
+          double* xo = Xp + (long)(k + 1) * 5;
+          xo[0] = in.p0x; xo[1] = in.v0x; xo[2] = in.p0y; xo[3] = in.v0y; xo[4] = in.th0;
+        }
+        k_done = k + 1;
+      }
+    }
+  }
+  if (in.valid && lane == 0) { n_steps[pb] = k_done; last_status[pb] = st_last; total_iters[pb] = it_sum; }
+}
 
 // host-side launcher of one instantiation (defined in lipmpc_inst.hip, one object per (G, NOBS_L))
 template <int G, int NOBS_L>
@@ -770,5 +880,10 @@ void launch_plan_step(const KArgs& k, long B, const double* state, const double*
                       const double* delta, const double* obs_xy, const int32_t* obs_nv, double* U, double* X,
                       double* theta, double* omega, double* obj, int32_t* status, int32_t* iters,
                       unsigned long long* active, double* c_eta, double* diag, hipStream_t stream);
+template <int G, int NOBS_L>
+void launch_rollout(const KArgs& k, long B, int k_max, int mpc_step, double stop_obj, const double* state0,
+                    const double* goal, const int8_t* first_foot, const double* delta, const double* obs_xy,
+                    const int32_t* obs_nv, double* X_pred, double* U_pred, int32_t* n_steps, int32_t* last_status,
+                    int32_t* total_iters, hipStream_t stream);
 
 }  // namespace lipmpc_dev

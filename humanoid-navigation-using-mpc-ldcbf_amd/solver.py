@@ -150,6 +150,26 @@ class BatchedLipMpc:
         _lib.check(rc, "lipmpc_advance_batch")
 
 
+    def rollout(self, state0, goal, first_foot, obs_xy=None, obs_nv=None, delta=None, k_max=100, mpc_step=1,
+                stop_obj=0.05):
+        """Closed loop on the device (HumanoidMpc.py:345-459) for B robots: returns dict(X_pred [B,k_max+1,5],
+        U_pred [B,k_max,3], n_steps [B], last_status [B], total_iters [B]); rows beyond n_steps are undefined."""
+        B = self._check_inputs(state0, goal, first_foot, obs_xy, obs_nv, delta)
+        dev = self.device
+        out = dict(X_pred=torch.empty((B, k_max + 1, 5), dtype=torch.float64, device=dev),
+                   U_pred=torch.empty((B, k_max, 3), dtype=torch.float64, device=dev),
+                   n_steps=torch.empty((B,), dtype=torch.int32, device=dev),
+                   last_status=torch.empty((B,), dtype=torch.int32, device=dev),
+                   total_iters=torch.empty((B,), dtype=torch.int32, device=dev))
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = self.lib.lipmpc_rollout_batch(self._h, B, int(k_max), int(mpc_step), float(stop_obj), _ptr(state0), _ptr(goal),
+                                           _ptr(first_foot), _ptr(delta), _ptr(obs_xy), _ptr(obs_nv), _ptr(out["X_pred"]),
+                                           _ptr(out["U_pred"]), _ptr(out["n_steps"]), _ptr(out["last_status"]),
+                                           _ptr(out["total_iters"]), C.c_void_p(stream))
+        _lib.check(rc, "lipmpc_rollout_batch")
+        return out
+
+
 def unpack_active(active_words: np.ndarray, num_rows: int) -> np.ndarray:
     """[B,words] int64/uint64 -> [B,num_rows] bool in canonical row order."""
     w = np.ascontiguousarray(active_words).view(np.uint64)

@@ -113,6 +113,23 @@ int lipmpc_advance_batch(lipmpc_handle* h, int64_t B, double* state, int8_t* fir
                          const double* U, const double* theta, const int32_t* status,
                          void* hip_stream);
 
+/* Closed loop on the device: HumanoidMPC.run_simulation (HumanoidMpc.py:345-459) for B robots, one group of
+ * lanes per robot for the whole run, no host round trip.  Per sample k < k_max: stop when the previous
+ * step's objective < stop_obj (0.05 in the reference, :392); on MPC samples (k % mpc_step == 0,
+ * mpc_step = max(1, int(DELTA_T / sampling_time)), :74-75) solve the step and advance x+ = A x + B u_0
+ * (:441-442), on the others only the heading moves (:443-447); a failed solve ends that robot's run
+ * (:419-429).  Uses the handle's flags (LIPMPC_FLAG_INTERIOR = advance with the interior iterate).
+ *  state0 [B,5], goal [B,2], first_foot [B], delta [B] or NULL, obs_xy/obs_nv as in lipmpc_plan_step_batch
+ * outputs
+ *  X_pred  [B,k_max+1,5]  (p_x,v_x,p_y,v_y,theta) per sample; rows 0..n_steps[b] are valid
+ *  U_pred  [B,k_max,3]    (f_x,f_y,omega) per sample;        rows 0..n_steps[b]-1 are valid
+ *  n_steps [B] samples completed, last_status [B] status of the last solve, total_iters [B] sum of IPM iterations
+ */
+int lipmpc_rollout_batch(lipmpc_handle* h, int64_t B, int32_t k_max, int32_t mpc_step, double stop_obj,
+                         const double* state0, const double* goal, const int8_t* first_foot, const double* delta,
+                         const double* obs_xy, const int32_t* obs_nv, double* X_pred, double* U_pred,
+                         int32_t* n_steps, int32_t* last_status, int32_t* total_iters, void* hip_stream);
+
 const char* lipmpc_strerror(int code);
 int lipmpc_version(void);
 
