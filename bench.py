@@ -147,12 +147,34 @@ def main():
                                  "achieved = SURVEY §8d dense F_iter x actual iterations / kernel time; the kernel "
                                  "applies G structurally and executes far fewer flops (DESIGN.md)"},
         }
+        if world == 1:
+            res["rollout"] = rollout_throughput(lipmpc, walker, obs_xy, obs_nv, goal, delta, dev)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(P, state, goal, foot, obs_xy, obs_nv, delta, out)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def rollout_throughput(lipmpc, walker, obs_xy, obs_nv, goal, delta, dev, k_max=40):
+    """Secondary figure (not `value`): the same robots walking k_max closed-loop MPC steps from rest in ONE
+    launch (lipmpc_rollout_batch).  No per-step batch barrier, so a wave pays the slowest of its own 4
+    robots per step instead of the slowest of the batch."""
+    B = obs_xy.shape[0]
+    st0 = torch.zeros((B, 5), dtype=torch.float64, device=dev)
+    ft0 = torch.ones((B,), dtype=torch.int8, device=dev)
+    walker.rollout(st0, goal, ft0, obs_xy, obs_nv, delta, k_max=k_max)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ro = walker.rollout(st0, goal, ft0, obs_xy, obs_nv, delta, k_max=k_max)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1)
+    steps = int(ro["n_steps"].sum().item())
+    return {"solves_per_s": steps / (ms * 1e-3), "ms": ms, "robots": B, "k_max": k_max, "mpc_steps_solved": steps,
+            "mean_iters_per_step": float(ro["total_iters"].sum().item()) / max(steps, 1)}
 
 
 def cpu_baseline(P, state, goal, foot, obs_xy, obs_nv, delta, out):
