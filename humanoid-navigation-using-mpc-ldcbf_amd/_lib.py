@@ -48,11 +48,11 @@ def load():
     lib.lipmpc_num_rows.restype = i64
     lib.lipmpc_active_words.argtypes = [C.POINTER(LipmpcParamsC)]
     lib.lipmpc_active_words.restype = i64
-    lib.lipmpc_plan_step_batch.argtypes = [vp, i64] + [vp] * 17
+    lib.lipmpc_plan_step_batch.argtypes = [vp, i64] + [vp] * 18
     lib.lipmpc_plan_step_batch.restype = i32
     lib.lipmpc_advance_batch.argtypes = [vp, i64] + [vp] * 6
     lib.lipmpc_advance_batch.restype = i32
-    lib.lipmpc_rollout_batch.argtypes = [vp, i64, C.c_int32, C.c_int32, C.c_double] + [vp] * 12
+    lib.lipmpc_rollout_batch.argtypes = [vp, i64, C.c_int32, C.c_int32, C.c_double] + [vp] * 13
     lib.lipmpc_rollout_batch.restype = i32
     lib.lipmpc_strerror.argtypes = [i32]
     lib.lipmpc_strerror.restype = C.c_char_p

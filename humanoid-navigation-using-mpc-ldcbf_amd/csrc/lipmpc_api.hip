@@ -85,13 +85,13 @@ void lipmpc_destroy(lipmpc_handle* h) { free(h); }
 
 #define LAUNCH(GG, NL)                                                                                         \
   launch_plan_step<GG, NL>(h->k, (long)B, state, goal, first_foot, delta, obs_xy, obs_nv, U, X, theta, omega, obj, \
-                           status, iters, (unsigned long long*)active, c_eta, diag, stream)
+                           status, iters, (unsigned long long*)active, c_eta, diag, bounds, stream)
 
 int lipmpc_plan_step_batch(lipmpc_handle* h, int64_t B, const double* state, const double* goal,
                            const int8_t* first_foot, const double* delta, const double* obs_xy,
                            const int32_t* obs_nv, double* U, double* X, double* theta, double* omega,
                            double* obj, int32_t* status, int32_t* iters, uint64_t* active, double* c_eta, double* diag,
-                           void* hip_stream) {
+                           const double* bounds, void* hip_stream) {
   if (!h || B < 0) return LIPMPC_E_ARG;
   if (B == 0) return LIPMPC_OK;
   if (!state || !goal || !first_foot || !U || !X || !theta || !omega || !obj || !status || !iters || !active)
@@ -121,12 +121,13 @@ int lipmpc_plan_step_batch(lipmpc_handle* h, int64_t B, const double* state, con
 
 #define LAUNCH_RO(GG, NL)                                                                                        \
   launch_rollout<GG, NL>(h->k, (long)B, k_max, mpc_step, stop_obj, state0, goal, first_foot, delta, obs_xy, obs_nv, \
-                         X_pred, U_pred, n_steps, last_status, total_iters, stream)
+                         X_pred, U_pred, n_steps, last_status, total_iters, bounds, stream)
 
 int lipmpc_rollout_batch(lipmpc_handle* h, int64_t B, int32_t k_max, int32_t mpc_step, double stop_obj,
                          const double* state0, const double* goal, const int8_t* first_foot, const double* delta,
                          const double* obs_xy, const int32_t* obs_nv, double* X_pred, double* U_pred,
-                         int32_t* n_steps, int32_t* last_status, int32_t* total_iters, void* hip_stream) {
+                         int32_t* n_steps, int32_t* last_status, int32_t* total_iters, const double* bounds,
+                         void* hip_stream) {
   if (!h || B < 0 || k_max < 1 || mpc_step < 1) return LIPMPC_E_ARG;
   if (B == 0) return LIPMPC_OK;
   if (!state0 || !goal || !first_foot || !X_pred || !U_pred || !n_steps || !last_status || !total_iters) return LIPMPC_E_ARG;

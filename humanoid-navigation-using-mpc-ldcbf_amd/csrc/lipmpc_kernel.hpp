@@ -212,6 +212,7 @@ constexpr int R_RU = 0, R_RL = 1, R_VU = 2, R_VL = 3, R_M = 4, R_CBF = 5;
 // one problem's inputs as the group sees them / what the closed loop needs back
 struct StepIn {
   double p0x, v0x, p0y, v0y, th0, gx, gy, foot0, delta;
+  double vmax_x, vmax_y, alpha_over_pi, omega_max;   // per-problem bounds (handle values unless overridden)
   long pb;          // problem index (obstacle arrays, step outputs)
   bool valid;       // false: padding group of the last workgroup (computes, never writes)
 };
@@ -219,6 +220,15 @@ struct StepOut {
   int status, iters;
   double ux, uy, theta1, omega0, obj;   // first footstep, next heading, first turning rate, objective
 };
+
+// per-problem overrides of (V_MAX_x, V_MAX_y, ALPHA, OMEGA_MAX) — the knobs bounds_tuning.py:17-26 sweeps
+__device__ __forceinline__ void load_bounds(const KArgs& P, const double* __restrict__ bounds, long pb, StepIn& in) {
+  in.vmax_x = P.v_max[0]; in.vmax_y = P.v_max[1]; in.alpha_over_pi = P.alpha_over_pi; in.omega_max = P.omega_max;
+  if (bounds) {
+    in.vmax_x = bounds[pb * 4 + 0]; in.vmax_y = bounds[pb * 4 + 1];
+    in.alpha_over_pi = bounds[pb * 4 + 2] * (1.0 / M_PI); in.omega_max = bounds[pb * 4 + 3];
+  }
+}
 
 // The whole MPC step of one problem on one group of G lanes.  Output pointers may be null.
 template <int G, int NOBS_L>
@@ -263,7 +273,7 @@ __device__ __forceinline__ StepOut step_body(
     double th = th0;
     if (valid && lane == 0 && theta_out) theta_out[pb * (N + 1)] = th0;
     for (int k = 0; k < N; ++k) {
-      double w = fmin(fmax(psi - th, -P.omega_max), P.omega_max);
+      double w = fmin(fmax(psi - th, -in.omega_max), in.omega_max);
       double thn = th + w * P.tau;
       if (k == a) { th_r = th; th_v = thn; om_a = w; }
       if (k == 0) { theta1 = thn; omega0 = w; }
@@ -326,8 +336,8 @@ __device__ __forceinline__ StepOut step_body(
 
   // bounds of the non-LDCBF rows
   const double hi_r = P.l_max[c], lo_r = P.l_min[c];
-  const double hi_v = P.v_max[c], lo_v = P.v_min[c];
-  const double hi_m = P.v_max[0] - P.alpha_over_pi * fabs(om_a);
+  const double hi_v = c ? in.vmax_y : in.vmax_x, lo_v = P.v_min[c];
+  const double hi_m = in.vmax_x - in.alpha_over_pi * fabs(om_a);
   // affine parts: reach r = rr.(p_{a+1} - p_a) + (c ? s_a*ell : 0); p_0 is a constant for a = 0
   const double r_c = (c ? foot_r * P.ell : 0.0) - ((a == 0) ? (rr0 * p0x + rr1 * p0y) : 0.0);
   // v_{a+1} = kappa x_a + 2 kappa (-1)^a sum_{j<a} (-1)^j x_j + (-1)^{a+1} (v_0 + kappa p_0)
@@ -783,13 +793,14 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
     double* __restrict__ U, double* __restrict__ X, double* __restrict__ theta_out,
     double* __restrict__ omega_out, double* __restrict__ obj_out, int32_t* __restrict__ status_out,
     int32_t* __restrict__ iters_out, unsigned long long* __restrict__ active_out, double* __restrict__ c_eta,
-    double* __restrict__ diag) {
+    double* __restrict__ diag, const double* __restrict__ bounds) {
   constexpr int GPW = 64 / G;
   const long prob_raw = (long)blockIdx.x * GPW + threadIdx.x / G;
   StepIn in;
   in.valid = prob_raw < B;
   const long pb = in.valid ? prob_raw : (B - 1);
   in.pb = pb;
+  load_bounds(P, bounds, pb, in);
   // every lane of the group reads the same 64 B: one broadcast transaction
   in.p0x = state[pb * 5 + 0]; in.v0x = state[pb * 5 + 1]; in.p0y = state[pb * 5 + 2]; in.v0y = state[pb * 5 + 3];
   in.th0 = state[pb * 5 + 4];
@@ -814,7 +825,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(
     const double* __restrict__ goal, const int8_t* __restrict__ first_foot, const double* __restrict__ delta_in,
     const double* __restrict__ obs_xy, const int32_t* __restrict__ obs_nv, double* __restrict__ X_pred,
     double* __restrict__ U_pred, int32_t* __restrict__ n_steps, int32_t* __restrict__ last_status,
-    int32_t* __restrict__ total_iters) {
+    int32_t* __restrict__ total_iters, const double* __restrict__ bounds) {
   constexpr int GPW = 64 / G;
   const int lane = threadIdx.x & (G - 1);
   const long prob_raw = (long)blockIdx.x * GPW + threadIdx.x / G;
@@ -822,6 +833,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(
   in.valid = prob_raw < B;
   const long pb = in.valid ? prob_raw : (B - 1);
   in.pb = pb;
+  load_bounds(P, bounds, pb, in);
   in.p0x = state0[pb * 5 + 0]; in.v0x = state0[pb * 5 + 1]; in.p0y = state0[pb * 5 + 2]; in.v0y = state0[pb * 5 + 3];
   in.th0 = state0[pb * 5 + 4];
   in.gx = goal[pb * 2 + 0]; in.gy = goal[pb * 2 + 1];
@@ -849,7 +861,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(
         else { last_obj = r.obj; ukx = r.ux; uky = r.uy; }
       } else {
         const double psi = atan2(in.gy - in.p0y, in.gx - in.p0x);
-        omega0 = fmin(fmax(psi - in.th0, -P.omega_max), P.omega_max);
+        omega0 = fmin(fmax(psi - in.th0, -in.omega_max), in.omega_max);
         theta1 = in.th0 + omega0 * P.tau;
       }
       if (!fin) {
@@ -879,11 +891,11 @@ template <int G, int NOBS_L>
 void launch_plan_step(const KArgs& k, long B, const double* state, const double* goal, const int8_t* first_foot,
                       const double* delta, const double* obs_xy, const int32_t* obs_nv, double* U, double* X,
                       double* theta, double* omega, double* obj, int32_t* status, int32_t* iters,
-                      unsigned long long* active, double* c_eta, double* diag, hipStream_t stream);
+                      unsigned long long* active, double* c_eta, double* diag, const double* bounds, hipStream_t stream);
 template <int G, int NOBS_L>
 void launch_rollout(const KArgs& k, long B, int k_max, int mpc_step, double stop_obj, const double* state0,
                     const double* goal, const int8_t* first_foot, const double* delta, const double* obs_xy,
                     const int32_t* obs_nv, double* X_pred, double* U_pred, int32_t* n_steps, int32_t* last_status,
-                    int32_t* total_iters, hipStream_t stream);
+                    int32_t* total_iters, const double* bounds, hipStream_t stream);
 
 }  // namespace lipmpc_dev

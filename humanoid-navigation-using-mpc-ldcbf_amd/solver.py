@@ -123,9 +123,10 @@ class BatchedLipMpc:
 
     # ---- the hot path -----------------------------------------------------------------------------
     def plan_step_batch(self, state, goal, first_foot, obs_xy=None, obs_nv=None, delta=None, out=None,
-                        with_c_eta=False, with_diag=False):
+                        with_c_eta=False, with_diag=False, bounds=None):
         """state [B,5] (px,vx,py,vy,theta), goal [B,2], first_foot [B] int8 (+1 right / -1 left),
-        obs_xy [B,n_obs_max,v_max,2] CCW rings, obs_nv [B,n_obs_max] int32, delta [B] or None.
+        obs_xy [B,n_obs_max,v_max,2] CCW rings, obs_nv [B,n_obs_max] int32, delta [B] or None,
+        bounds [B,4] (V_MAX_x, V_MAX_y, ALPHA, OMEGA_MAX) per problem or None.
         Returns dict(U,X,theta,omega,obj,status,iters,active[,c_eta]) of device tensors; results are
         valid once the current stream is synchronised."""
         B = self._check_inputs(state, goal, first_foot, obs_xy, obs_nv, delta)
@@ -136,7 +137,7 @@ class BatchedLipMpc:
             self._h, B, _ptr(state), _ptr(goal), _ptr(first_foot), _ptr(delta), _ptr(obs_xy), _ptr(obs_nv),
             _ptr(out["U"]), _ptr(out["X"]), _ptr(out["theta"]), _ptr(out["omega"]), _ptr(out["obj"]),
             _ptr(out["status"]), _ptr(out["iters"]), _ptr(out["active"]), _ptr(out.get("c_eta")),
-            _ptr(out.get("diag")), C.c_void_p(stream))
+            _ptr(out.get("diag")), _ptr(bounds), C.c_void_p(stream))
         _lib.check(rc, "lipmpc_plan_step_batch")
         return out
 
@@ -151,7 +152,7 @@ class BatchedLipMpc:
 
 
     def rollout(self, state0, goal, first_foot, obs_xy=None, obs_nv=None, delta=None, k_max=100, mpc_step=1,
-                stop_obj=0.05):
+                stop_obj=0.05, bounds=None):
         """Closed loop on the device (HumanoidMpc.py:345-459) for B robots: returns dict(X_pred [B,k_max+1,5],
         U_pred [B,k_max,3], n_steps [B], last_status [B], total_iters [B]); rows beyond n_steps are undefined."""
         B = self._check_inputs(state0, goal, first_foot, obs_xy, obs_nv, delta)
@@ -165,7 +166,7 @@ class BatchedLipMpc:
         rc = self.lib.lipmpc_rollout_batch(self._h, B, int(k_max), int(mpc_step), float(stop_obj), _ptr(state0), _ptr(goal),
                                            _ptr(first_foot), _ptr(delta), _ptr(obs_xy), _ptr(obs_nv), _ptr(out["X_pred"]),
                                            _ptr(out["U_pred"]), _ptr(out["n_steps"]), _ptr(out["last_status"]),
-                                           _ptr(out["total_iters"]), C.c_void_p(stream))
+                                           _ptr(out["total_iters"]), _ptr(bounds), C.c_void_p(stream))
         _lib.check(rc, "lipmpc_rollout_batch")
         return out
 

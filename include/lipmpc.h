@@ -96,6 +96,8 @@ int64_t lipmpc_active_words(const lipmpc_params* p);
  *  theta  [B,N+1]    omega [B,N]                obj [B] objective incl. the constant k=0 term
  *  status [B]  iters [B]  active [B,lipmpc_active_words]  bit i = canonical row i in the certified active set
  *  c_eta  [B,n_obs_max,4] (c_x,c_y,eta_x,eta_y) or NULL
+ *  bounds [B,4] or NULL: per-problem (V_MAX_x, V_MAX_y, ALPHA, OMEGA_MAX) replacing the handle's values —
+ *         the knobs the reference's bounds_tuning sweep mutates in `conf` (bounds_tuning.py:17-26)
  *  diag   [B,4] or NULL: (active-set rounds used, final equality residual of the finish,
  *         identification margin min_i |log(z_i/s_i)| of the interior-point phase, final mu)
  */
@@ -104,7 +106,7 @@ int lipmpc_plan_step_batch(lipmpc_handle* h, int64_t B,
                            const double* delta, const double* obs_xy, const int32_t* obs_nv,
                            double* U, double* X, double* theta, double* omega, double* obj,
                            int32_t* status, int32_t* iters, uint64_t* active, double* c_eta, double* diag,
-                           void* hip_stream);
+                           const double* bounds, void* hip_stream);
 
 /* Closed-loop state advance (HumanoidMpc.py:432-447): for problems with status SOLVED/UNCERTIFIED
  * state <- (A_l x + B_l U[b,0], theta[b,1]), first_foot <- -first_foot; others are left untouched.
@@ -128,7 +130,8 @@ int lipmpc_advance_batch(lipmpc_handle* h, int64_t B, double* state, int8_t* fir
 int lipmpc_rollout_batch(lipmpc_handle* h, int64_t B, int32_t k_max, int32_t mpc_step, double stop_obj,
                          const double* state0, const double* goal, const int8_t* first_foot, const double* delta,
                          const double* obs_xy, const int32_t* obs_nv, double* X_pred, double* U_pred,
-                         int32_t* n_steps, int32_t* last_status, int32_t* total_iters, void* hip_stream);
+                         int32_t* n_steps, int32_t* last_status, int32_t* total_iters, const double* bounds,
+                         void* hip_stream);
 
 const char* lipmpc_strerror(int code);
 int lipmpc_version(void);

@@ -152,9 +152,12 @@ typedef struct {
 } work_t;
 
 /* One problem.  Layouts as in include/lipmpc.h. */
-static void plan_one(const lipmpc_params* P, work_t* W, const double* st, const double* goal, int foot0, double delta,
+static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, const double* st, const double* goal, int foot0, double delta,
                      const double* obs_xy, const int32_t* obs_nv, double* U, double* X, double* theta, double* omega,
                      double* obj, int32_t* status_out, int32_t* iters_out, uint64_t* active, double* c_eta, double* diag) {
+  lipmpc_params Pl = *P0;   /* per-problem (V_MAX_x, V_MAX_y, ALPHA, OMEGA_MAX) overrides, bounds_tuning.py:17-26 */
+  if (bnd) { Pl.v_max_xy[0] = bnd[0]; Pl.v_max_xy[1] = bnd[1]; Pl.alpha = bnd[2]; Pl.omega_max = bnd[3]; }
+  const lipmpc_params* P = &Pl;
   const int N = P->N, n = 2 * N, n_obs = P->n_obs_max;
   const double beta = sqrt(P->g / P->h_com), ch = cosh(beta * P->dt), sh = sinh(beta * P->dt);
   const double kap = beta * sh / (ch - 1.0);
@@ -405,7 +408,7 @@ int lipmpc_oracle_plan_step_batch(const lipmpc_params* P, int64_t B, const doubl
                                   const int8_t* first_foot, const double* delta, const double* obs_xy,
                                   const int32_t* obs_nv, double* U, double* X, double* theta, double* omega,
                                   double* obj, int32_t* status, int32_t* iters, uint64_t* active, double* c_eta,
-                                  double* diag, int n_threads) {
+                                  double* diag, const double* bounds, int n_threads) {
   if (!P || P->N < 1 || P->N > 16 || P->n_obs_max < 0 || P->n_obs_max > 50) return LIPMPC_E_UNSUPPORTED;
   const int N = P->N, n_obs = P->n_obs_max;
   const int64_t words = (9 * N + (N + 1) * n_obs + 63) / 64;
@@ -422,7 +425,7 @@ int lipmpc_oracle_plan_step_batch(const lipmpc_params* P, int64_t B, const doubl
     if (!err) {
 #pragma omp for schedule(dynamic, 8)
       for (int64_t b = 0; b < B; ++b) {
-        plan_one(P, W, state + b * 5, goal + b * 2, (int)first_foot[b], delta ? delta[b] : 0.0,
+        plan_one(P, bounds ? bounds + b * 4 : NULL, W, state + b * 5, goal + b * 2, (int)first_foot[b], delta ? delta[b] : 0.0,
                  obs_xy ? obs_xy + (size_t)b * n_obs * P->v_max * 2 : NULL, obs_nv ? obs_nv + b * n_obs : NULL,
                  U + b * N * 2, X + b * (N + 1) * 4, theta + b * (N + 1), omega + b * N, obj + b, status + b, iters + b,
                  active + b * words, c_eta ? c_eta + (size_t)b * n_obs * 4 : NULL, diag ? diag + b * 4 : NULL);
