@@ -241,7 +241,13 @@ __device__ __forceinline__ StepOut step_body(
   constexpr int NMAX = G / 2;          // stages a group can hold
   constexpr int NV = G;                // variable slots (lanes)
   constexpr int GPW = 64 / G;          // groups per wavefront
-  constexpr int NR = R_CBF + NOBS_L;   // local row slots
+  // LDCBF rows of a lane live in registers for small obstacle sets (NOBS_R of them) and are STREAMED for
+  // large ones: only (s, z) per row is kept, in LDS, and every pass over the rows recomputes the rest from
+  // the obstacle's (eta, b) in LDS and the stage's position — no per-row register state, no spills.
+  constexpr bool STREAM = NOBS_L > 5;
+  constexpr int NOBS_R = STREAM ? 0 : NOBS_L;
+  constexpr int NOBS_S = STREAM ? NOBS_L : 0;
+  constexpr int NR = R_CBF + NOBS_R;   // local row slots held in registers
   constexpr int MAXOBS = 2 * NOBS_L;
   constexpr int MAXWORDS = 16;         // (9*16 + 17*50 + 63)/64 = 16
 
@@ -249,6 +255,7 @@ __device__ __forceinline__ StepOut step_body(
   __shared__ double lds_P[GPW][NMAX][2][2];                     // P_b blocks of the velocity part of K
   __shared__ unsigned long long lds_act[GPW][MAXWORDS];
   __shared__ int lds_flag[GPW];
+  __shared__ double lds_sz[GPW][NOBS_S > 0 ? NOBS_S : 1][G][2];   // streamed rows: (s, z) then (s, y); lane-contiguous
 
   const int tid = threadIdx.x;
   const int lane = tid & (G - 1);
@@ -294,7 +301,11 @@ __device__ __forceinline__ StepOut step_body(
   if (lane == 0) lds_flag[grp] = 0;
   __syncthreads();
   if (MAXOBS > 0) {
-    for (int j = lane; j < P.n_obs; j += G) {
+    for (int j = lane; j < MAXOBS; j += G) {
+      if (j >= P.n_obs) {      // unused slot: absent (h0 = +inf), harmless values
+        lds_obs[grp][j][0] = 0.0; lds_obs[grp][j][1] = 0.0; lds_obs[grp][j][2] = 0.0; lds_obs[grp][j][3] = INFINITY;
+        continue;
+      }
       const long oidx = pb * P.n_obs + j;
       const int nv = obs_nv[oidx];
       double cx = 0, cy = 0, ex = 0, ey = 0, bb = 0, h0 = INFINITY;
@@ -306,9 +317,7 @@ __device__ __forceinline__ StepOut step_body(
         h0 = (ex * p0x + ey * p0y) - ec - delta;
         if (degen) atomicOr(&lds_flag[grp], 2);
         else if (h0 < -P.k0_tol) atomicOr(&lds_flag[grp], 1);
-      } else {
-        ex = 0.0; ey = 0.0; bb = -INFINITY;   // marks an empty slot
-      }
+      }                                          // nv == 0: empty slot, h0 stays +inf
       lds_obs[grp][j][0] = ex; lds_obs[grp][j][1] = ey; lds_obs[grp][j][2] = bb; lds_obs[grp][j][3] = h0;
       if (c_eta && valid) {
         double* o = c_eta + oidx * 4;
@@ -320,17 +329,24 @@ __device__ __forceinline__ StepOut step_body(
   const int front_flag = lds_flag[grp];
 
   // per-lane LDCBF rows: obstacle j = 2t + c
-  double oex[NOBS_L > 0 ? NOBS_L : 1], oey[NOBS_L > 0 ? NOBS_L : 1], ob[NOBS_L > 0 ? NOBS_L : 1];
+  double oex[NOBS_R > 0 ? NOBS_R : 1], oey[NOBS_R > 0 ? NOBS_R : 1], ob[NOBS_R > 0 ? NOBS_R : 1];
   bool pres[NR];
 #pragma unroll
-  for (int t = 0; t < NOBS_L; ++t) {
+  for (int t = 0; t < NOBS_R; ++t) {
     const int j = 2 * t + c;
-    const bool on = var_on && j < P.n_obs;
-    double e0 = 0, e1 = 0, b2 = -INFINITY;
-    if (j < P.n_obs) { e0 = lds_obs[grp][j][0]; e1 = lds_obs[grp][j][1]; b2 = lds_obs[grp][j][2]; }
-    pres[R_CBF + t] = on && (b2 != -INFINITY);
-    oex[t] = e0; oey[t] = e1; ob[t] = pres[R_CBF + t] ? b2 : 0.0;
+    oex[t] = lds_obs[grp][j][0]; oey[t] = lds_obs[grp][j][1]; ob[t] = lds_obs[grp][j][2];
+    pres[R_CBF + t] = var_on && (lds_obs[grp][j][3] != INFINITY);
   }
+  // streamed rows: presence bits, accessors
+  unsigned pbits = 0u;
+#pragma unroll
+  for (int t = 0; t < NOBS_S; ++t)
+    if (var_on && lds_obs[grp][2 * t + c][3] != INFINITY) pbits |= 1u << t;
+  auto s_obs = [&](int t, double& ex, double& ey, double& b) {
+    const double* o = lds_obs[grp][2 * t + c];
+    ex = o[0]; ey = o[1]; b = o[2];
+  };
+  auto s_pm = [&](int t) -> double { return ((pbits >> t) & 1u) ? 1.0 : 0.0; };
   pres[R_RU] = pres[R_RL] = pres[R_VU] = pres[R_VL] = var_on;
   pres[R_M] = var_on && (c == 0);
 
@@ -344,16 +360,17 @@ __device__ __forceinline__ StepOut step_body(
   const double vcx = -sgn_a * (v0x + kap * p0x), vcy = -sgn_a * (v0y + kap * p0y);
   const double w_c = wv0 * vcx + wv1 * vcy;
 
-  int n_rows_l = 0;
+  int n_rows_l = __popc(pbits);
 #pragma unroll
   for (int i = 0; i < NR; ++i) n_rows_l += pres[i] ? 1 : 0;
   const double m_rows = gsum<G>((double)n_rows_l);
 
   // ---- linear row maps -------------------------------------------------------------------------
   // rows(x): lin[R_RU] = rr.(x_a - x_{a-1}); lin[R_VU] = wv.v_a(x); lin[R_CBF+t] = eta_t . x_a
-  auto rows_lin = [&](double x, double& r_lin, double& w_lin, double (&h_lin)[NOBS_L > 0 ? NOBS_L : 1]) {
+  auto rows_lin = [&](double x, double& r_lin, double& w_lin, double (&h_lin)[NOBS_R > 0 ? NOBS_R : 1], double& xx,
+                      double& xy) {
     const double xp = gxor<G, 1>(x);
-    const double xx = c ? xp : x, xy = c ? x : xp;
+    xx = c ? xp : x; xy = c ? x : xp;
     double pxx = gup<G, 2>(xx, lane), pxy = gup<G, 2>(xy, lane);
     if (a == 0) { pxx = 0.0; pxy = 0.0; }
     r_lin = rr0 * (xx - pxx) + rr1 * (xy - pxy);
@@ -363,10 +380,11 @@ __device__ __forceinline__ StepOut step_body(
     const double vx = c ? vlp : vl, vy = c ? vl : vlp;
     w_lin = wv0 * vx + wv1 * vy;
 #pragma unroll
-    for (int t = 0; t < NOBS_L; ++t) h_lin[t] = oex[t] * xx + oey[t] * xy;
+    for (int t = 0; t < NOBS_R; ++t) h_lin[t] = oex[t] * xx + oey[t] * xy;
   };
   // (G^T w)_lane from direction weights: tr (reach dir), tv (velocity dir), wc[t] (LDCBF rows, g = -eta)
-  auto GT_apply = [&](double tr, double tv, const double (&wc)[NOBS_L > 0 ? NOBS_L : 1]) -> double {
+  // (axs, ays): sum_t eta_t w_t over this lane's streamed rows
+  auto GT_apply = [&](double tr, double tv, const double (&wc)[NOBS_R > 0 ? NOBS_R : 1], double axs, double ays) -> double {
     const double trp = gxor<G, 1>(tr);
     const double t0 = c ? trp : tr, t1 = c ? tr : trp;
     const double reach_own = c ? (sr * t0 + cr * t1) : (cr * t0 - sr * t1);
@@ -379,9 +397,9 @@ __device__ __forceinline__ StepOut step_body(
     const double uu = var_on ? u : 0.0;
     const double suf = suffix_excl2<G>(sgn_a * uu, lane);
     res += kap * uu + 2.0 * kap * sgn_a * suf;
-    double ax = 0.0, ay = 0.0;
+    double ax = axs, ay = ays;
 #pragma unroll
-    for (int t = 0; t < NOBS_L; ++t) { ax += oex[t] * wc[t]; ay += oey[t] * wc[t]; }
+    for (int t = 0; t < NOBS_R; ++t) { ax += oex[t] * wc[t]; ay += oey[t] * wc[t]; }
     const double recv = gxor<G, 1>(c ? ax : ay);
     res -= (c ? ay : ax) + recv;
     return var_on ? res : 0.0;
@@ -393,7 +411,8 @@ __device__ __forceinline__ StepOut step_body(
 #pragma unroll
   for (int b = 0; b < NMAX; ++b) eqm[b] = (b == a) ? 1.0 : 0.0;
   // dr = d_RU + d_RL, dv = d_VU + d_VL (+ d_M), dc[t] = LDCBF row weights
-  auto form_K = [&](double dr, double dv, const double (&dc)[NOBS_L > 0 ? NOBS_L : 1]) {
+  // (cxs, cxys, cys): sum_t d_t eta_t eta_t^T over this lane's streamed rows
+  auto form_K = [&](double dr, double dv, const double (&dc)[NOBS_R > 0 ? NOBS_R : 1], double cxs, double cxys, double cys) {
     const double drp = gxor<G, 1>(dr);
     const double d0 = c ? drp : dr, d1 = c ? dr : drp;
     // F = Rr^T diag(d0,d1) Rr, Rr = [[cr,sr],[-sr,cr]]; this lane keeps row c
@@ -409,9 +428,9 @@ __device__ __forceinline__ StepOut step_body(
     const double k2 = kap * kap;
     const double Pc0 = 2.0 * k2 * Ec0 + 4.0 * k2 * S0, Pc1 = 2.0 * k2 * Ec1 + 4.0 * k2 * S1;
     lds_P[grp][a][c][0] = Pc0; lds_P[grp][a][c][1] = Pc1;
-    double cxx = 0.0, cxy = 0.0, cyy = 0.0;
+    double cxx = cxs, cxy = cxys, cyy = cys;
 #pragma unroll
-    for (int t = 0; t < NOBS_L; ++t) { cxx += dc[t] * oex[t] * oex[t]; cxy += dc[t] * oex[t] * oey[t]; cyy += dc[t] * oey[t] * oey[t]; }
+    for (int t = 0; t < NOBS_R; ++t) { cxx += dc[t] * oex[t] * oex[t]; cxy += dc[t] * oex[t] * oey[t]; cyy += dc[t] * oey[t] * oey[t]; }
     cxx += gxor<G, 1>(cxx); cxy += gxor<G, 1>(cxy); cyy += gxor<G, 1>(cyy);
     const double Cc0 = c ? cxy : cxx, Cc1 = c ? cyy : cxy;
     // F_{a+1}, row c (0 past the last stage: lanes without rows have d = 0, hence F = 0)
@@ -480,36 +499,37 @@ __device__ __forceinline__ StepOut step_body(
   // ---- interior point ---------------------------------------------------------------------------
   double q = var_on ? p0c : 0.0;
   double s[NR], z[NR], slk[NR];     // slack variable, multiplier, slack function value h - g.q
-  double hl[NOBS_L > 0 ? NOBS_L : 1];
+  double hl[NOBS_R > 0 ? NOBS_R : 1];
+  double cx_, cy_;                   // stage position / direction of the last rows_lin call (both coordinates)
   auto slack_values = [&](double x) {
     double r_lin, w_lin;
-    rows_lin(x, r_lin, w_lin, hl);
+    rows_lin(x, r_lin, w_lin, hl, cx_, cy_);
     const double r = r_lin + r_c, w = w_lin + w_c;
     slk[R_RU] = hi_r - r; slk[R_RL] = r - lo_r;
     slk[R_VU] = hi_v - w; slk[R_VL] = w - lo_v;
     slk[R_M] = hi_m - w;
 #pragma unroll
-    for (int t = 0; t < NOBS_L; ++t) slk[R_CBF + t] = hl[t] - ob[t];
+    for (int t = 0; t < NOBS_R; ++t) slk[R_CBF + t] = hl[t] - ob[t];
   };
   // g_i . dx for every local row from the linear maps
   auto rows_dir = [&](double dx, double (&dl)[NR]) {
     double r_lin, w_lin;
-    rows_lin(dx, r_lin, w_lin, hl);
+    rows_lin(dx, r_lin, w_lin, hl, cx_, cy_);
     dl[R_RU] = r_lin; dl[R_RL] = -r_lin; dl[R_VU] = w_lin; dl[R_VL] = -w_lin; dl[R_M] = w_lin;
 #pragma unroll
-    for (int t = 0; t < NOBS_L; ++t) dl[R_CBF + t] = -hl[t];
+    for (int t = 0; t < NOBS_R; ++t) dl[R_CBF + t] = -hl[t];
   };
-  auto GT_rows = [&](const double (&w)[NR]) -> double {
-    double wc[NOBS_L > 0 ? NOBS_L : 1];
+  auto GT_rows = [&](const double (&w)[NR], double axs, double ays) -> double {
+    double wc[NOBS_R > 0 ? NOBS_R : 1];
 #pragma unroll
-    for (int t = 0; t < NOBS_L; ++t) wc[t] = w[R_CBF + t];
-    return GT_apply(w[R_RU] - w[R_RL], w[R_VU] - w[R_VL] + w[R_M], wc);
+    for (int t = 0; t < NOBS_R; ++t) wc[t] = w[R_CBF + t];
+    return GT_apply(w[R_RU] - w[R_RL], w[R_VU] - w[R_VL] + w[R_M], wc, axs, ays);
   };
-  auto K_rows = [&](const double (&d)[NR]) {
-    double dc[NOBS_L > 0 ? NOBS_L : 1];
+  auto K_rows = [&](const double (&d)[NR], double cxs, double cxys, double cys) {
+    double dc[NOBS_R > 0 ? NOBS_R : 1];
 #pragma unroll
-    for (int t = 0; t < NOBS_L; ++t) dc[t] = d[R_CBF + t];
-    form_K(d[R_RU] + d[R_RL], d[R_VU] + d[R_VL] + d[R_M], dc);
+    for (int t = 0; t < NOBS_R; ++t) dc[t] = d[R_CBF + t];
+    form_K(d[R_RU] + d[R_RL], d[R_VU] + d[R_VL] + d[R_M], dc, cxs, cxys, cys);
   };
 
   slack_values(q);
@@ -518,6 +538,30 @@ __device__ __forceinline__ StepOut step_body(
     s[i] = pres[i] ? fmax(slk[i], IPM_S_FLOOR) : 1.0;
     z[i] = pres[i] ? IPM_Z0 : 0.0;
   }
+  if constexpr (STREAM) {
+#pragma unroll 1
+    for (int t = 0; t < NOBS_S; ++t) {
+      double ex, ey, b;
+      s_obs(t, ex, ey, b);
+      const bool on = (pbits >> t) & 1u;
+      lds_sz[grp][t][lane][0] = on ? fmax(ex * cx_ + ey * cy_ - b, IPM_S_FLOOR) : 1.0;
+      lds_sz[grp][t][lane][1] = on ? IPM_Z0 : 0.0;
+    }
+  }
+  // One streamed row as every pass sees it: (s, z) from LDS, the rest recomputed from (eta, b) and the
+  // stage position (px, py) of the current iterate.
+  struct SRow { double s, z, rp, is, d, ex, ey, pm; };
+  auto s_row = [&](int t, double px, double py) -> SRow {
+    SRow r;
+    double b;
+    s_obs(t, r.ex, r.ey, b);
+    r.pm = s_pm(t);
+    r.s = lds_sz[grp][t][lane][0]; r.z = lds_sz[grp][t][lane][1];
+    r.rp = (r.s - (r.ex * px + r.ey * py - b)) * r.pm;
+    r.is = fast_rcp(r.s);
+    r.d = r.z * r.is;
+    return r;
+  };
 
   int status = LIPMPC_STATUS_MAX_ITER;
   int iters = 0;
@@ -546,7 +590,24 @@ __device__ __forceinline__ StepOut step_body(
         rpmax_l = fmax(rpmax_l, fabs(rp[i]));
         zmax_l = fmax(zmax_l, z[i]);
       }
-      const double mu = gsum<G>(mu_l) / m_rows;
+      // streamed rows, pass A: residual statistics, K blocks and predictor weights in one sweep
+      double qx = 0.0, qy = 0.0, cxs = 0.0, cxys = 0.0, cys = 0.0, axs = 0.0, ays = 0.0;
+      if constexpr (STREAM) {
+        const double qp = gxor<G, 1>(q);
+        qx = c ? qp : q; qy = c ? q : qp;
+#pragma unroll 1
+        for (int t = 0; t < NOBS_S; ++t) {
+          const SRow r = s_row(t, qx, qy);
+          mu_l = fma(r.s, r.z, mu_l);
+          rpmax_l = fmax(rpmax_l, fabs(r.rp));
+          zmax_l = fmax(zmax_l, r.z);
+          cxs = fma(r.d * r.ex, r.ex, cxs); cxys = fma(r.d * r.ex, r.ey, cxys); cys = fma(r.d * r.ey, r.ey, cys);
+          const double wt = fma(r.d, r.rp - r.s, r.z);            // z + d (rp - s)
+          axs = fma(r.ex, wt, axs); ays = fma(r.ey, wt, ays);
+        }
+      }
+      const double musum = gsum<G>(mu_l);
+      const double mu = musum / m_rows;
       const double rpmax = gmax<G>(rpmax_l);
       const double zq = gmax<G>(fmax(zmax_l * (1.0 / IPM_Z_DIVERGE), fabs(q) * 1e-300));   // >= 1: diverged
       const bool bad = !(zq < 1.0);
@@ -564,7 +625,7 @@ __device__ __forceinline__ StepOut step_body(
           iz_[i] = __builtin_amdgcn_rcp(fmax(z[i], 1e-300));
           d[i] = z[i] * is_[i];
         }
-        K_rows(d);
+        K_rows(d, cxs, cxys, cys);
         const bool fok = factor();
         if (!fok) {
           // K loses numerical definiteness once max(z/s) ~ 1e15: near the solution that is
@@ -577,21 +638,33 @@ __device__ __forceinline__ StepOut step_body(
         const double m2qg = var_on ? -2.0 * (q - gc) : 0.0;
 #pragma unroll
         for (int i = 0; i < NR; ++i) w[i] = fma(d[i], rp[i] - s[i], z[i]);
-        double dq = solve(m2qg - GT_rows(w));
+        const double dqa = solve(m2qg - GT_rows(w, axs, ays));
         double dl[NR], dsa[NR], dza[NR];
-        rows_dir(dq, dl);
+        rows_dir(dqa, dl);
+        const double ax_ = cx_, ay_ = cy_;                  // predictor direction of this stage (both coordinates)
         double r_l = 1.0;                                  // largest of 1, -ds/s, -dz/z
+        double s1_l = 0.0, s2_l = 0.0;                     // sum(s dz + z ds), sum(ds dz): mu_aff is a polynomial in the step
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
           dsa[i] = (-rp[i] - dl[i]) * pm[i];
           dza[i] = -d[i] * (s[i] + dsa[i]);               // -(s z + z ds)/s
           r_l = fmax(r_l, fmax(-dsa[i] * is_[i], -dza[i] * iz_[i]));
+          s1_l = fma(s[i], dza[i], fma(z[i], dsa[i], s1_l));
+          s2_l = fma(dsa[i], dza[i], s2_l);
+        }
+        if constexpr (STREAM) {                            // pass B
+#pragma unroll 1
+          for (int t = 0; t < NOBS_S; ++t) {
+            const SRow r = s_row(t, qx, qy);
+            const double dsa_t = (-r.rp + (r.ex * ax_ + r.ey * ay_)) * r.pm;      // g = -eta
+            const double dza_t = -r.d * (r.s + dsa_t);
+            r_l = fmax(r_l, fmax(-dsa_t * r.is, -dza_t * __builtin_amdgcn_rcp(fmax(r.z, 1e-300))));
+            s1_l = fma(r.s, dza_t, fma(r.z, dsa_t, s1_l));
+            s2_l = fma(dsa_t, dza_t, s2_l);
+          }
         }
         const double a_aff = 1.0 / gmax<G>(r_l);
-        double mua_l = 0.0;
-#pragma unroll
-        for (int i = 0; i < NR; ++i) mua_l = fma(fma(a_aff, dsa[i], s[i]), fma(a_aff, dza[i], z[i]), mua_l);
-        const double mu_aff = gsum<G>(mua_l) / m_rows;
+        const double mu_aff = fma(a_aff, fma(a_aff, gsum<G>(s2_l), gsum<G>(s1_l)), musum) / m_rows;
         const double ratio = mu_aff / mu;
         const double sigma_mu = ratio * ratio * ratio * mu;
         // corrector: rc = s z + ds_a dz_a - sigma mu
@@ -601,8 +674,21 @@ __device__ __forceinline__ StepOut step_body(
           rc[i] = (fma(s[i], z[i], dsa[i] * dza[i]) - sigma_mu) * pm[i];
           w[i] = fma(fma(z[i], rp[i], -rc[i]), is_[i], z[i]);
         }
-        dq = solve(m2qg - GT_rows(w));
+        axs = 0.0; ays = 0.0;
+        if constexpr (STREAM) {                            // pass D
+#pragma unroll 1
+          for (int t = 0; t < NOBS_S; ++t) {
+            const SRow r = s_row(t, qx, qy);
+            const double dsa_t = (-r.rp + (r.ex * ax_ + r.ey * ay_)) * r.pm;
+            const double dza_t = -r.d * (r.s + dsa_t);
+            const double rc_t = (fma(r.s, r.z, dsa_t * dza_t) - sigma_mu) * r.pm;
+            const double wt = fma(fma(r.z, r.rp, -rc_t), r.is, r.z);
+            axs = fma(r.ex, wt, axs); ays = fma(r.ey, wt, ays);
+          }
+        }
+        const double dq = solve(m2qg - GT_rows(w, axs, ays));
         rows_dir(dq, dl);
+        const double bx_ = cx_, by_ = cy_;                  // corrector direction of this stage
         r_l = IPM_STEP_FRAC;                               // alpha = min(1, 0.995 / max ratio)
         double ds[NR], dz[NR];
 #pragma unroll
@@ -611,8 +697,35 @@ __device__ __forceinline__ StepOut step_body(
           dz[i] = -fma(z[i], ds[i], rc[i]) * is_[i];
           r_l = fmax(r_l, fmax(-ds[i] * is_[i], -dz[i] * iz_[i]));
         }
+        // streamed rows: (ds, dz) of the combined direction, recomputed identically in passes E and F
+        auto s_step = [&](const SRow& r, double& ds_t, double& dz_t) {
+          const double dsa_t = (-r.rp + (r.ex * ax_ + r.ey * ay_)) * r.pm;
+          const double dza_t = -r.d * (r.s + dsa_t);
+          const double rc_t = (fma(r.s, r.z, dsa_t * dza_t) - sigma_mu) * r.pm;
+          ds_t = (-r.rp + (r.ex * bx_ + r.ey * by_)) * r.pm;
+          dz_t = -fma(r.z, ds_t, rc_t) * r.is;
+        };
+        if constexpr (STREAM) {                            // pass E
+#pragma unroll 1
+          for (int t = 0; t < NOBS_S; ++t) {
+            const SRow r = s_row(t, qx, qy);
+            double ds_t, dz_t;
+            s_step(r, ds_t, dz_t);
+            r_l = fmax(r_l, fmax(-ds_t * r.is, -dz_t * __builtin_amdgcn_rcp(fmax(r.z, 1e-300))));
+          }
+        }
         const double alpha = IPM_STEP_FRAC / gmax<G>(r_l);
         if (!done) {
+          if constexpr (STREAM) {                          // pass F (before q moves: rows are evaluated at the old iterate)
+#pragma unroll 1
+            for (int t = 0; t < NOBS_S; ++t) {
+              const SRow r = s_row(t, qx, qy);
+              double ds_t, dz_t;
+              s_step(r, ds_t, dz_t);
+              lds_sz[grp][t][lane][0] = fma(alpha, ds_t, r.s);
+              lds_sz[grp][t][lane][1] = fma(alpha, dz_t, r.z);
+            }
+          }
           q = fma(alpha, dq, q);
           // slack functions are affine in q: h - g.(q + a dq) = slk - a g.dq (recomputed from q in the finish)
 #pragma unroll
@@ -624,20 +737,44 @@ __device__ __forceinline__ StepOut step_body(
     }
   }
 
-  // diagnostics: identification margin min |log(z/s)| and final mu of the interior-point phase
+  // canonical row index (include/lipmpc.h) of a local row slot / of streamed row t
+  auto ci_of = [&](int i) -> int {
+    if (i == R_RU) return 4 * a + c;
+    if (i == R_RL) return 4 * a + 2 + c;
+    if (i == R_VU) return 5 * N + 4 * a + c;
+    if (i == R_VL) return 5 * N + 4 * a + 2 + c;
+    if (i == R_M) return 4 * N + a;
+    return 9 * N + (a + 1) * P.n_obs + 2 * (i - R_CBF) + c;
+  };
+  auto ci_s = [&](int t) -> int { return 9 * N + (a + 1) * P.n_obs + 2 * t + c; };
+
+  // diagnostics: identification margin min |log(z/(1e5 s))| and final mu of the interior-point phase;
+  // initial working set z > 1e5 s
   double marg_l = INFINITY, mufin_l = 0.0;
+  bool act[NR];
+  unsigned abits = 0u;
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
     if (pres[i]) { marg_l = fmin(marg_l, fabs(log(z[i] / (FIN_IDENT * s[i])))); mufin_l += s[i] * z[i]; }
+    act[i] = pres[i] && (z[i] > FIN_IDENT * s[i]);
   }
+  if constexpr (STREAM) {
+#pragma unroll 1
+    for (int t = 0; t < NOBS_S; ++t) {
+      if ((pbits >> t) & 1u) {
+        const double st = lds_sz[grp][t][lane][0], zt = lds_sz[grp][t][lane][1];
+        marg_l = fmin(marg_l, fabs(log(zt / (FIN_IDENT * st))));
+        mufin_l += st * zt;
+        if (zt > FIN_IDENT * st) abits |= 1u << t;
+      }
+    }
+  }
+  const unsigned fbits = abits;          // fallback working set of an uncertified finish
   const double margin = gmin<G>(marg_l);
   const double mu_fin = gsum<G>(mufin_l) / fmax(m_rows, 1.0);
   double diag_rounds = 0.0, diag_eres = 0.0;
 
   // ---- certified active-set finish --------------------------------------------------------------
-  bool act[NR];
-#pragma unroll
-  for (int i = 0; i < NR; ++i) act[i] = pres[i] && (z[i] > FIN_IDENT * s[i]);
   const bool ipm_ok = (status == LIPMPC_STATUS_SOLVED) && (m_rows > 0.0);
   if (!(P.flags & LIPMPC_FLAG_INTERIOR)) {
     bool fin_done = !ipm_ok;        // groups that never converged skip the finish
@@ -646,17 +783,33 @@ __device__ __forceinline__ StepOut step_body(
     double y[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) y[i] = act[i] ? z[i] : 0.0;
-    // canonical row index of each local slot (argmin tie-break and the active mask)
+    if constexpr (STREAM) {           // the z slot of a streamed row now holds its multiplier y
+#pragma unroll 1
+      for (int t = 0; t < NOBS_S; ++t)
+        if (!((abits >> t) & 1u)) lds_sz[grp][t][lane][1] = 0.0;
+    }
     for (int rnd = 0; rnd < FIN_ROUNDS; ++rnd) {
       if (__all(fin_done)) break;
       double d[NR];
 #pragma unroll
       for (int i = 0; i < NR; ++i) d[i] = act[i] ? FIN_RHO : 0.0;
-      K_rows(d);
+      double cxs = 0.0, cxys = 0.0, cys = 0.0;
+      if constexpr (STREAM) {
+#pragma unroll 1
+        for (int t = 0; t < NOBS_S; ++t) {
+          if ((abits >> t) & 1u) {
+            double ex, ey, bb;
+            s_obs(t, ex, ey, bb);
+            cxs = fma(FIN_RHO * ex, ex, cxs); cxys = fma(FIN_RHO * ex, ey, cxys); cys = fma(FIN_RHO * ey, ey, cys);
+          }
+        }
+      }
+      K_rows(d, cxs, cxys, cys);
       const bool fok = factor();
       double eres = INFINITY;
       for (int in = 0; in <= FIN_INNER; ++in) {
         slack_values(qf);
+        const double fx = cx_, fy = cy_;               // stage position of qf
         double wr[NR], rmax_l = 0.0;
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
@@ -664,18 +817,45 @@ __device__ __forceinline__ StepOut step_body(
           wr[i] = FIN_RHO * r;
           rmax_l = fmax(rmax_l, fabs(r));
         }
-        const double gty = GT_rows(y);
+        double ayx = 0.0, ayy = 0.0, awx = 0.0, awy = 0.0;
+        if constexpr (STREAM) {
+#pragma unroll 1
+          for (int t = 0; t < NOBS_S; ++t) {
+            if ((abits >> t) & 1u) {
+              double ex, ey, bb;
+              s_obs(t, ex, ey, bb);
+              const double r = -(ex * fx + ey * fy - bb);
+              const double yt = lds_sz[grp][t][lane][1];
+              rmax_l = fmax(rmax_l, fabs(r));
+              ayx = fma(ex, yt, ayx); ayy = fma(ey, yt, ayy);
+              awx = fma(ex, FIN_RHO * r, awx); awy = fma(ey, FIN_RHO * r, awy);
+            }
+          }
+        }
+        const double gty = GT_rows(y, ayx, ayy);
         const double rd = var_on ? (2.0 * (qf - gc) + gty) : 0.0;
         eres = fmax(gmax<G>(fabs(rd)), gmax<G>(rmax_l));
         const bool stop = (eres <= FIN_INNER_TOL) || (in == FIN_INNER);
         if (__all(stop || fin_done)) break;
-        const double dq = solve(-rd - GT_rows(wr));
+        const double dq = solve(-rd - GT_rows(wr, awx, awy));
         double dl[NR];
         rows_dir(dq, dl);
         if (!stop && !fin_done) {
           qf += dq;
 #pragma unroll
           for (int i = 0; i < NR; ++i) if (act[i]) y[i] += FIN_RHO * (dl[i] - slk[i]);
+          if constexpr (STREAM) {
+            const double ddx = cx_, ddy = cy_;
+#pragma unroll 1
+            for (int t = 0; t < NOBS_S; ++t) {
+              if ((abits >> t) & 1u) {
+                double ex, ey, bb;
+                s_obs(t, ex, ey, bb);
+                const double slk_t = ex * fx + ey * fy - bb, dl_t = -(ex * ddx + ey * ddy);
+                lds_sz[grp][t][lane][1] += FIN_RHO * (dl_t - slk_t);
+              }
+            }
+          }
         }
       }
       slack_values(qf);
@@ -684,12 +864,27 @@ __device__ __forceinline__ StepOut step_body(
       int yi = 0x7fffffff, si = 0x7fffffff;
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
-        int ci;
-        if (i == R_RU) ci = 4 * a + c; else if (i == R_RL) ci = 4 * a + 2 + c;
-        else if (i == R_VU) ci = 5 * N + 4 * a + c; else if (i == R_VL) ci = 5 * N + 4 * a + 2 + c;
-        else if (i == R_M) ci = 4 * N + a; else ci = 9 * N + (a + 1) * P.n_obs + 2 * (i - R_CBF) + c;
+        const int ci = ci_of(i);
         if (act[i] && (y[i] < ymin || (y[i] == ymin && ci < yi))) { ymin = y[i]; yi = ci; }
         if (pres[i] && !act[i] && (slk[i] < smin || (slk[i] == smin && ci < si))) { smin = slk[i]; si = ci; }
+      }
+      if constexpr (STREAM) {
+        const double fx = cx_, fy = cy_;
+#pragma unroll 1
+        for (int t = 0; t < NOBS_S; ++t) {
+          if ((pbits >> t) & 1u) {
+            const int ci = ci_s(t);
+            if ((abits >> t) & 1u) {
+              const double yt = lds_sz[grp][t][lane][1];
+              if (yt < ymin || (yt == ymin && ci < yi)) { ymin = yt; yi = ci; }
+            } else {
+              double ex, ey, bb;
+              s_obs(t, ex, ey, bb);
+              const double slk_t = ex * fx + ey * fy - bb;
+              if (slk_t < smin || (slk_t == smin && ci < si)) { smin = slk_t; si = ci; }
+            }
+          }
+        }
       }
       gargmin<G>(ymin, yi);
       gargmin<G>(smin, si);
@@ -697,21 +892,19 @@ __device__ __forceinline__ StepOut step_body(
       if (!fin_done) {
         if (ymin < -FIN_EPS) {
 #pragma unroll
-          for (int i = 0; i < NR; ++i) {
-            int ci;
-            if (i == R_RU) ci = 4 * a + c; else if (i == R_RL) ci = 4 * a + 2 + c;
-            else if (i == R_VU) ci = 5 * N + 4 * a + c; else if (i == R_VL) ci = 5 * N + 4 * a + 2 + c;
-            else if (i == R_M) ci = 4 * N + a; else ci = 9 * N + (a + 1) * P.n_obs + 2 * (i - R_CBF) + c;
-            if (act[i] && ci == yi) { act[i] = false; y[i] = 0.0; }
+          for (int i = 0; i < NR; ++i) if (act[i] && ci_of(i) == yi) { act[i] = false; y[i] = 0.0; }
+          if constexpr (STREAM) {
+#pragma unroll 1
+            for (int t = 0; t < NOBS_S; ++t)
+              if (((abits >> t) & 1u) && ci_s(t) == yi) { abits &= ~(1u << t); lds_sz[grp][t][lane][1] = 0.0; }
           }
         } else if (smin < -FIN_EPS) {
 #pragma unroll
-          for (int i = 0; i < NR; ++i) {
-            int ci;
-            if (i == R_RU) ci = 4 * a + c; else if (i == R_RL) ci = 4 * a + 2 + c;
-            else if (i == R_VU) ci = 5 * N + 4 * a + c; else if (i == R_VL) ci = 5 * N + 4 * a + 2 + c;
-            else if (i == R_M) ci = 4 * N + a; else ci = 9 * N + (a + 1) * P.n_obs + 2 * (i - R_CBF) + c;
-            if (pres[i] && !act[i] && ci == si) act[i] = true;
+          for (int i = 0; i < NR; ++i) if (pres[i] && !act[i] && ci_of(i) == si) act[i] = true;
+          if constexpr (STREAM) {
+#pragma unroll 1
+            for (int t = 0; t < NOBS_S; ++t)
+              if (((pbits >> t) & 1u) && !((abits >> t) & 1u) && ci_s(t) == si) abits |= 1u << t;
           }
         } else {
           fin_done = true;
@@ -728,6 +921,7 @@ __device__ __forceinline__ StepOut step_body(
         status = LIPMPC_STATUS_UNCERTIFIED;
 #pragma unroll
         for (int i = 0; i < NR; ++i) act[i] = pres[i] && (z[i] > FIN_IDENT * s[i]);
+        abits = fbits;
       }
     }
   }
@@ -747,11 +941,15 @@ __device__ __forceinline__ StepOut step_body(
   if (have_sol) {
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-      int ci;
-      if (i == R_RU) ci = 4 * a + c; else if (i == R_RL) ci = 4 * a + 2 + c;
-      else if (i == R_VU) ci = 5 * N + 4 * a + c; else if (i == R_VL) ci = 5 * N + 4 * a + 2 + c;
-      else if (i == R_M) ci = 4 * N + a; else ci = 9 * N + (a + 1) * P.n_obs + 2 * (i - R_CBF) + c;
+      const int ci = ci_of(i);
       if (act[i]) atomicOr(&lds_act[grp][ci >> 6], 1ull << (ci & 63));
+    }
+    if constexpr (STREAM) {
+#pragma unroll 1
+      for (int t = 0; t < NOBS_S; ++t) {
+        const int ci = ci_s(t);
+        if ((abits >> t) & 1u) atomicOr(&lds_act[grp][ci >> 6], 1ull << (ci & 63));
+      }
     }
   }
   __syncthreads();
