@@ -410,3 +410,35 @@ def test_bounds_tuning_sweep_in_one_launch():
         assert np.max(np.abs(Xh[b, : m + 1].T - Xo[:, : m + 1])) < 1e-6, b
         if Xo.shape[1] - 1 < 100:                                # a robot that dies early dies at the same sample
             assert abs(n_np[b] - (Xo.shape[1] - 1)) <= 4, (b, n_np[b], Xo.shape[1] - 1)
+
+
+def test_edge_shapes_and_ragged_inputs(golden_dir):
+    """Batch sizes that do not fill a wavefront (1, 2, 3, 5 problems; 4 or 2 problems share a wave), horizons
+    1 and 2, 24-vertex rings (v_max = 32) next to triangles with empty obstacle slots in between, B = 0."""
+    import c_oracle
+    circles = load_rings(os.path.join(golden_dir, "scenario_circles.npz"))      # 9-, 19- and 24-gons
+    tri = np.array([[7.0, 7.0], [8.0, 7.0], [7.5, 8.0]])
+    for N in (1, 2, 3):
+        for B in (1, 2, 3, 5):
+            probs = []
+            for b in range(B):
+                obs = [circles[b % 3], tri] if b % 2 == 0 else [tri]            # second slot empty on odd problems
+                probs.append((np.array([0.1 * b, 0.0, 3.0 - 0.2 * b, 0.0, -0.1 * b]), (6.0, -3.0), 1 if b % 2 == 0 else -1, obs, 0.05 * b))
+            res = run_gpu(probs, N, 2, 32)
+            P = lipmpc.LipMpcParams(N=N, n_obs_max=2, v_max=32)
+            xy, nv = lipmpc.pack_rings([p[3] for p in probs], 2, 32)
+            ref = c_oracle.plan_step_batch(P, np.array([p[0] for p in probs]), np.array([p[1] for p in probs], float),
+                                           np.array([p[2] for p in probs], np.int8), xy, nv,
+                                           np.array([p[4] for p in probs], float))
+            assert np.array_equal(res["status"], ref["status"]), (N, B)
+            ok = ref["status"] == 0
+            assert ok.all()
+            assert np.max(np.abs(res["U"] - ref["U"])) < 1e-8 and np.max(np.abs(res["X"] - ref["X"])) < 1e-8
+            assert np.array_equal(res["c_eta"], ref["c_eta"])
+            assert np.array_equal(lipmpc.unpack_active(res["active"], P.num_rows), lipmpc.unpack_active(ref["active"], P.num_rows))
+    # B = 0 is a no-op, not an error
+    sv = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=3))
+    out = sv.plan_step_batch(torch.zeros((0, 5), dtype=torch.float64, device="cuda"),
+                             torch.zeros((0, 2), dtype=torch.float64, device="cuda"),
+                             torch.zeros((0,), dtype=torch.int8, device="cuda"))
+    assert out["U"].shape == (0, 3, 2)
