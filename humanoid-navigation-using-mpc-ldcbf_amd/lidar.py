@@ -1,0 +1,98 @@
+"""LiDAR front end of the unknown-environment variant (BASELINE config 5) — host wrapper of
+lipmpc_lidar_sense_batch and the drop-in HumanoidMPCUnknownEnvironment class
+(HumanoidNavigation/MPC/HumanoidMPCVariants/HumanoidMPCUnknownEnvironment.py:13-68)."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .compat import HumanoidMPC, _ring_of
+from .solver import _ptr
+
+NOISE_STD = 0.01           # range_finder_wth_polygons_dbscan.py:163
+DBSCAN_EPS = 0.3           # :100
+DBSCAN_MIN_SAMPLES = 3     # :100
+
+
+def ray_table(resolution=360):
+    """(cos, sin) of i * 2 pi / resolution through math.cos / math.sin, as the reference computes its rays (:28-36)."""
+    step = 2 * math.pi / resolution
+    return np.array([[math.cos(i * step), math.sin(i * step)] for i in range(resolution)])
+
+
+class LidarSensor:
+    """Batched range_finder(): scan -> noise -> DBSCAN -> hulls, one wavefront per robot, rings in the layout
+    BatchedLipMpc.plan_step_batch consumes."""
+
+    def __init__(self, env_rings, lidar_range=3.0, resolution=360, n_obs_max=12, v_max=32, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("lipmpc needs a HIP device; there is no CPU path")
+        self.lib = _lib.load()
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self.lidar_range, self.resolution, self.n_obs_max, self.v_max = float(lidar_range), int(resolution), n_obs_max, v_max
+        rings = [np.asarray(r, float) for r in env_rings]
+        self.n_env = len(rings)
+        self.v_env = max([1] + [len(r) for r in rings])
+        xy = np.zeros((max(self.n_env, 1), self.v_env, 2)); nv = np.zeros(max(self.n_env, 1), np.int32)
+        for j, r in enumerate(rings):
+            xy[j, :len(r)] = r; nv[j] = len(r)
+        self.env_xy = torch.as_tensor(xy, device=self.device)
+        self.env_nv = torch.as_tensor(nv, device=self.device)
+        self.table = torch.as_tensor(ray_table(self.resolution), device=self.device)
+
+    def sense(self, state, noise=None, with_debug=False):
+        """state [B,5] device tensor; noise [B,resolution,2] or None -> dict(obs_xy, obs_nv, n_inferred, overflow[, hits, labels])."""
+        B, dev = state.shape[0], self.device
+        out = dict(obs_xy=torch.zeros((B, self.n_obs_max, self.v_max, 2), dtype=torch.float64, device=dev),
+                   obs_nv=torch.zeros((B, self.n_obs_max), dtype=torch.int32, device=dev),
+                   n_inferred=torch.zeros((B,), dtype=torch.int32, device=dev),
+                   overflow=torch.zeros((B,), dtype=torch.int32, device=dev))
+        if with_debug:
+            out["hits"] = torch.empty((B, self.resolution, 2), dtype=torch.float64, device=dev)
+            out["labels"] = torch.empty((B, self.resolution), dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = self.lib.lipmpc_lidar_sense_batch(
+            self.device_index, B, self.resolution, self.n_env, self.v_env, 1, self.lidar_range, DBSCAN_EPS,
+            DBSCAN_MIN_SAMPLES, self.n_obs_max, self.v_max, _ptr(state), _ptr(self.env_xy), _ptr(self.env_nv),
+            _ptr(self.table), _ptr(noise), _ptr(out["obs_xy"]), _ptr(out["obs_nv"]), _ptr(out["n_inferred"]),
+            _ptr(out["overflow"]), _ptr(out.get("hits")), _ptr(out.get("labels")), C.c_void_p(stream))
+        _lib.check(rc, "lipmpc_lidar_sense_batch")
+        return out
+
+
+class HumanoidMPCUnknownEnvironment(HumanoidMPC):
+    """The robot only perceives obstacles through its LiDAR (HumanoidMPCUnknownEnvironment.py:13-28): every sample the
+    obstacle set is re-inferred on the GPU and handed to the step solver.  ``noise_seed`` seeds the readings' noise
+    (the reference's is unseeded); ``noise_seed=None`` = noiseless readings."""
+
+    def __init__(self, goal, obstacles, N_horizon=3, N_mpc_timesteps=100, sampling_time=1e-3, init_state=None,
+                 start_with_right_foot: bool = True, verbosity: int = 1, lidar_range: float = 3.0,
+                 lidar_resolution: int = 360, noise_seed: int | None = 0, **kw):
+        self.lidar_range, self.lidar_resolution = lidar_range, lidar_resolution
+        super().__init__(goal, obstacles, N_horizon, N_mpc_timesteps, sampling_time,
+                         np.zeros(5) if init_state is None else init_state, start_with_right_foot, verbosity, **kw)
+        # the reference scans `ch.points` (raw input order), HumanoidMPCUnknownEnvironment.py:46
+        env = [np.asarray(o.points, float) if hasattr(o, "points") else np.asarray(o, float) for o in obstacles]
+        self._sensor = LidarSensor(env, lidar_range, lidar_resolution, device=self._device)
+        self._gen = None if noise_seed is None else torch.Generator(device=self._sensor.device).manual_seed(int(noise_seed))
+        self.list_inferred_obstacles = []
+
+    def _get_obstacle_rings(self, x_k: float, y_k: float):
+        dev = self._sensor.device
+        st = torch.tensor([[x_k, 0.0, y_k, 0.0, 0.0]], dtype=torch.float64, device=dev)
+        noise = None
+        if self._gen is not None:
+            noise = NOISE_STD * torch.randn((1, self.lidar_resolution, 2), dtype=torch.float64, device=dev, generator=self._gen)
+        out = self._sensor.sense(st, noise)
+        torch.cuda.synchronize(dev)
+        n = int(out["n_inferred"][0])
+        nv = out["obs_nv"][0].cpu().numpy()
+        xy = out["obs_xy"][0].cpu().numpy()
+        rings = [xy[j, :nv[j]].copy() for j in range(n)]
+        self.list_inferred_obstacles.append(rings)
+        return rings

@@ -133,6 +133,30 @@ int lipmpc_rollout_batch(lipmpc_handle* h, int64_t B, int32_t k_max, int32_t mpc
                          int32_t* n_steps, int32_t* last_status, int32_t* total_iters, const double* bounds,
                          void* hip_stream);
 
+/* Unknown-environment front end (BASELINE config 5): what HumanoidMPCUnknownEnvironment._get_list_c_and_eta does
+ * before the closest-point step (HumanoidMPCUnknownEnvironment.py:30-55): range_finder() =
+ * compute_lidar_readings -> Gaussian noise -> DBSCAN(eps, min_samples) -> convex hull per cluster
+ * (RangeFinder/range_finder_wth_polygons_dbscan.py:26-63, 100-126, 157-180).  One wavefront per robot; the rings
+ * come out in the layout lipmpc_plan_step_batch takes as obs_xy / obs_nv.
+ *  state      [B,5]  only (p_x, p_y) are read
+ *  env_xy     [n_env,v_env,2] if env_shared else [B,n_env,v_env,2]; env_nv likewise: the TRUE map as vertex rings
+ *             in the order the reference iterates them (`ch.points`, HumanoidMPCUnknownEnvironment.py:46)
+ *  ray_table  [resolution,2] (cos, sin) of angle_i = i * 2 pi / resolution, computed on the host (bit-identical
+ *             directions to the reference's math.cos / math.sin); resolution <= 384
+ *  noise      [B,resolution,2] added to valid readings, or NULL.  The reference draws N(0, 0.01) from numpy's
+ *             global, unseeded generator (:162-172); here the caller supplies the (seeded) sample.
+ * outputs
+ *  obs_xy [B,n_obs_max,v_max,2], obs_nv [B,n_obs_max]: CCW rings of the inferred obstacles, cluster order
+ *  n_inferred [B]; overflow [B] = 1 if clusters/vertices did not fit (n_obs_max, v_max)
+ *  hits [B,resolution,2] (NaN = no reading) or NULL; labels [B,resolution] (-2 no reading, -1 noise, k cluster) or NULL
+ */
+int lipmpc_lidar_sense_batch(int device, int64_t B, int32_t resolution, int32_t n_env, int32_t v_env,
+                             int32_t env_shared, double lidar_range, double eps, int32_t min_samples,
+                             int32_t n_obs_max, int32_t v_max, const double* state, const double* env_xy,
+                             const int32_t* env_nv, const double* ray_table, const double* noise,
+                             double* obs_xy, int32_t* obs_nv, int32_t* n_inferred, int32_t* overflow,
+                             double* hits, int32_t* labels, void* hip_stream);
+
 const char* lipmpc_strerror(int code);
 int lipmpc_version(void);
 

@@ -1,0 +1,124 @@
+"""LiDAR front end (BASELINE config 5).  CPU: the oracle restatement against vectors produced by the reference's own
+range_finder / scikit-learn / Qhull (tests/golden/lidar_golden.npz).  GPU: lipmpc_lidar_sense_batch against both."""
+import os
+
+import numpy as np
+import pytest
+
+import lidar_oracle as L
+
+
+def _case(d, i):
+    rings = [d["env"][i][j][: d["env_nv"][i][j]] for j in range(d["env"].shape[1]) if d["env_nv"][i][j] > 0]
+    return d["pos"][i], rings, float(d["lidar_range"][i])
+
+
+def _same_ring(a, b):
+    if len(a) != len(b):
+        return False
+    k = int(np.argmin(np.abs(b - a[0]).sum(1)))
+    return np.array_equal(np.roll(b, -k, axis=0), a)
+
+
+def test_oracle_matches_reference_range_finder(golden_dir):
+    d = np.load(os.path.join(golden_dir, "lidar_golden.npz"))
+    tab = L.ray_table()
+    for i in range(0, len(d["pos"]), 3):
+        pos, rings, rng = _case(d, i)
+        hits, valid = L.lidar_hits(pos, rings, rng, tab)
+        assert np.array_equal(valid, d["valid"][i])
+        assert np.array_equal(hits[valid], d["clean"][i][valid])                 # hit points bit-exact
+        _, _, labels, inferred = L.range_finder(pos, rings, rng, noise=d["noise"][i], table=tab)
+        assert np.array_equal(labels, d["labels"][i][valid])                      # scikit-learn's DBSCAN labels
+        n_ref = int((d["inf_nv"][i] > 0).sum())
+        assert len(inferred) == n_ref
+        for j, ring in enumerate(inferred):                                        # Qhull's rings (any rotation)
+            assert _same_ring(ring, d["inf_xy"][i][j][: d["inf_nv"][i][j]])
+
+
+def test_dbscan_border_and_noise_rules():
+    # two 3-point cores 0.5 apart with one border point within eps of both: it joins the first-discovered cluster
+    pts = np.array([[0.0, 0.0], [0.1, 0.0], [0.2, 0.0], [0.45, 0.0], [0.7, 0.0], [0.8, 0.0], [0.9, 0.0], [3.0, 3.0]])
+    from sklearn.cluster import DBSCAN
+    ref = DBSCAN(eps=0.3, min_samples=3).fit(pts).labels_
+    assert np.array_equal(L.dbscan_labels(pts), ref)
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        p = rng.uniform(0, 3, (int(rng.integers(5, 120)), 2))
+        assert np.array_equal(L.dbscan_labels(p), DBSCAN(eps=0.3, min_samples=3).fit(p).labels_)
+
+
+def test_hull_rules():
+    assert L.hull_ring(np.array([[0.0, 0], [1, 1], [2, 2], [3, 3]])) is None        # collinear (rank test, :75)
+    assert L.hull_ring(np.array([[0.0, 0], [1, 1], [0, 0]])) is None                # < 3 unique points (:70)
+    r = L.hull_ring(np.array([[0.0, 0], [1, 0], [2, 0], [2, 2], [0, 2], [1, 1], [1, 0]]))
+    assert np.array_equal(r, np.array([[0.0, 0], [2, 0], [2, 2], [0, 2]]))          # CCW, edge midpoint dropped
+
+
+@pytest.mark.gpu
+def test_gpu_lidar_matches_reference_and_oracle(golden_dir):
+    torch = pytest.importorskip("torch")
+    import lipmpc
+    d = np.load(os.path.join(golden_dir, "lidar_golden.npz"))
+    n_bad = 0
+    for i in range(len(d["pos"])):
+        pos, rings, rng = _case(d, i)
+        sensor = lipmpc.LidarSensor(rings, lidar_range=rng, resolution=360, n_obs_max=12, v_max=40)
+        st = torch.tensor([[pos[0], 0.0, pos[1], 0.0, 0.0]], dtype=torch.float64, device="cuda")
+        noise = torch.as_tensor(d["noise"][i][None], device="cuda")
+        out = sensor.sense(st, noise, with_debug=True)
+        torch.cuda.synchronize()
+        hits = out["hits"][0].cpu().numpy()
+        valid = ~np.isnan(hits[:, 0])
+        assert np.array_equal(valid, d["valid"][i])
+        assert np.array_equal(hits[valid], (d["clean"][i] + d["noise"][i])[valid])        # bit-exact readings
+        assert np.array_equal(out["labels"][0].cpu().numpy(), d["labels"][i])              # scikit-learn's labels
+        n = int(out["n_inferred"][0]); nv = out["obs_nv"][0].cpu().numpy(); xy = out["obs_xy"][0].cpu().numpy()
+        assert int(out["overflow"][0]) == 0
+        assert n == int((d["inf_nv"][i] > 0).sum())
+        for j in range(n):
+            ref = d["inf_xy"][i][j][: d["inf_nv"][i][j]]
+            assert _same_ring(xy[j, : nv[j]], ref), (i, j)
+    assert n_bad == 0
+
+
+@pytest.mark.gpu
+def test_gpu_unknown_environment_step_end_to_end(golden_dir):
+    """scan -> rings -> plan_step on the device against lidar oracle -> step oracle, many robots on one shared map."""
+    torch = pytest.importorskip("torch")
+    import lipmpc
+    import lipmpc_oracle as O
+    d = np.load(os.path.join(golden_dir, "lidar_golden.npz"))
+    _, rings, _ = _case(d, 0)
+    rng = np.random.default_rng(3)
+    B, N = 96, 3
+    pos = []
+    while len(pos) < B:
+        p = rng.uniform(-0.5, 5.5, 2)
+        if not any(O.point_in_ring(p, r) for r in rings):
+            pos.append(p)
+    pos = np.array(pos)
+    st = np.zeros((B, 5)); st[:, 0] = pos[:, 0]; st[:, 2] = pos[:, 1]
+    noise = 0.01 * rng.standard_normal((B, 360, 2))
+    sensor = lipmpc.LidarSensor(rings, lidar_range=1.5, n_obs_max=12, v_max=32)
+    d_st = torch.as_tensor(st, device="cuda")
+    sen = sensor.sense(d_st, torch.as_tensor(noise, device="cuda"))
+    P = lipmpc.LipMpcParams(N=N, n_obs_max=12, v_max=32)
+    sv = lipmpc.BatchedLipMpc(P)
+    goal = torch.tensor([[5.0, 5.0]], dtype=torch.float64, device="cuda").repeat(B, 1).contiguous()
+    foot = torch.ones((B,), dtype=torch.int8, device="cuda")
+    out = sv.plan_step_batch(d_st, goal, foot, sen["obs_xy"], sen["obs_nv"], None)
+    torch.cuda.synchronize()
+    assert int(sen["overflow"].sum()) == 0
+    U, status = out["U"].cpu().numpy(), out["status"].cpu().numpy()
+    tab = L.ray_table()
+    n_ok = 0
+    for b in range(B):
+        _, _, _, inferred = L.range_finder(pos[b], rings, 1.5, noise=noise[b], table=tab)
+        r = O.plan_step(st[b], (5.0, 5.0), 1, inferred, 0.0, O.Params(N=N))
+        assert int(sen["n_inferred"][b]) == len(inferred)
+        assert status[b] == r["status"], (b, status[b], r["status"])
+        if r["status"] == 0:
+            n_ok += 1
+            assert np.max(np.abs(U[b] - r["U"])) < 1e-7
+    assert n_ok > 0.7 * B
