@@ -122,3 +122,43 @@ def test_gpu_unknown_environment_step_end_to_end(golden_dir):
             n_ok += 1
             assert np.max(np.abs(U[b] - r["U"])) < 1e-7
     assert n_ok > 0.7 * B
+
+
+@pytest.mark.gpu
+def test_gpu_unknown_environment_class_and_throughput(golden_dir):
+    """The drop-in HumanoidMPCUnknownEnvironment walks a CROWDED map it only sees through the scanner, and the
+    batched pipeline (scan + step for 4096 robots on one map) is timed for the record."""
+    torch = pytest.importorskip("torch")
+    import lipmpc
+    import lipmpc_oracle as O
+    d = np.load(os.path.join(golden_dir, "lidar_golden.npz"))
+    _, rings, _ = _case(d, 0)
+    mpc = lipmpc.HumanoidMPCUnknownEnvironment(goal=(5, 5), obstacles=rings, N_horizon=3, N_mpc_timesteps=60,
+                                               sampling_time=0.4, init_state=(-0.8, 0, -0.8, 0, 0.7), verbosity=0,
+                                               lidar_range=1.5, noise_seed=1)
+    X, U, _ = mpc.run_simulation(None, make_fast_plot=False, fill_animator=False)
+    assert X.shape[1] >= 10 and len(mpc.list_inferred_obstacles) >= 10
+    for k in range(X.shape[1]):                                  # never inside a true obstacle
+        assert not any(O.point_in_ring((X[0, k], X[2, k]), r) for r in rings)
+    assert np.hypot(X[0, -1] - 5, X[2, -1] - 5) < np.hypot(X[0, 0] - 5, X[2, 0] - 5)   # and it made progress
+    # batched: 4096 robots on the shared map
+    B = 4096
+    rng = np.random.default_rng(0)
+    pos = rng.uniform(-0.8, 5.8, (B, 2))
+    st = np.zeros((B, 5)); st[:, 0] = pos[:, 0]; st[:, 2] = pos[:, 1]
+    d_st = torch.as_tensor(st, device="cuda")
+    sensor = lipmpc.LidarSensor(rings, lidar_range=1.5, n_obs_max=12, v_max=32)
+    noise = 0.01 * torch.randn((B, 360, 2), dtype=torch.float64, device="cuda")
+    sv = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=3, n_obs_max=12, v_max=32))
+    goal = torch.tensor([[5.0, 5.0]], dtype=torch.float64, device="cuda").repeat(B, 1).contiguous()
+    foot = torch.ones((B,), dtype=torch.int8, device="cuda")
+    for _ in range(2):
+        sen = sensor.sense(d_st, noise); out = sv.plan_step_batch(d_st, goal, foot, sen["obs_xy"], sen["obs_nv"], None)
+    torch.cuda.synchronize()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    e[0].record(); sen = sensor.sense(d_st, noise); e[1].record()
+    out = sv.plan_step_batch(d_st, goal, foot, sen["obs_xy"], sen["obs_nv"], None); e[2].record()
+    torch.cuda.synchronize()
+    print(f"config 5, B={B}: scan {e[0].elapsed_time(e[1]):.3f} ms + step {e[1].elapsed_time(e[2]):.3f} ms; "
+          f"inferred obstacles mean {float(sen['n_inferred'].double().mean()):.2f}, overflow {int(sen['overflow'].sum())}")
+    assert int(sen["overflow"].sum()) == 0
