@@ -54,6 +54,7 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
   __shared__ int root_[RMAX];                    // cluster root of every reading (NO_ROOT = noise)
   __shared__ unsigned long long nb_[RMAX][WORDS];
   __shared__ int roots_[64];
+  __shared__ int cand_[RMAX];                    // obstacles that can be hit from here, list order
 
   const int lane = threadIdx.x;
   const long b = blockIdx.x;
@@ -61,8 +62,31 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
   const double x0 = state[b * 5 + 0], y0 = state[b * 5 + 2];
   const double* exy = env_xy + b * env_stride * (long)n_env * v_env * 2;
   const int32_t* env = env_nv + b * env_stride * (long)n_env;
+  int n_cand = 0;
 
   // ---- 1. ray casting (compute_lidar_readings) ---------------------------------------------------
+  // candidate obstacles: those whose bounding circle comes within the range (conservative: an obstacle that is
+  // skipped cannot hold a point closer than lidar_range), compacted once per robot in list order
+  for (int j0 = 0; j0 < n_env; j0 += 64) {
+    const int j = j0 + lane;
+    bool keep = false;
+    if (j < n_env) {
+      const int nv = env[j];
+      const double* ring = exy + (long)j * v_env * 2;
+      double mx = 0.0, my = 0.0;
+      for (int e = 0; e < nv; ++e) { mx += ring[2 * e]; my += ring[2 * e + 1]; }
+      if (nv > 0) {
+        mx /= nv; my /= nv;
+        double rad = 0.0;
+        for (int e = 0; e < nv; ++e) rad = fmax(rad, hypot(ring[2 * e] - mx, ring[2 * e + 1] - my));
+        keep = hypot(mx - x0, my - y0) <= (lidar_range + rad) * (1.0 + 1e-9) + 1e-9;
+      }
+    }
+    const unsigned long long ball = __ballot(keep);
+    if (keep) { const int k = n_cand + __popcll(ball & ((1ull << lane) - 1ull)); if (k < RMAX) cand_[k] = j; }
+    n_cand += __popcll(ball);
+  }
+  __syncthreads();
   for (int i = lane; i < RMAX; i += 64) {
     bool have = false;
     double hx = 0.0, hy = 0.0;
@@ -71,7 +95,8 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
       const double ex = x0 + lidar_range * ray_table[2 * i], ey = y0 + lidar_range * ray_table[2 * i + 1];
       const double rdx = ex - x0, rdy = ey - y0;               // b1 - a1
       double best_d = lidar_range;
-      for (int j = 0; j < n_env; ++j) {
+      for (int jc = 0; jc < n_cand; ++jc) {
+        const int j = cand_[jc];
         const int nv = env[j];
         const double* ring = exy + (long)j * v_env * 2;
         bool chave = false;
@@ -82,8 +107,15 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
           const double b2x = ring[2 * e1], b2y = ring[2 * e1 + 1];
           const double denom = (b2y - a2y) * rdx - (b2x - a2x) * rdy;
           if (denom == 0.0) continue;
-          const double ua = ((b2x - a2x) * (y0 - a2y) - (b2y - a2y) * (x0 - a2x)) / denom;
-          const double ub = (rdx * (y0 - a2y) - rdy * (x0 - a2x)) / denom;
+          const double nua = (b2x - a2x) * (y0 - a2y) - (b2y - a2y) * (x0 - a2x);
+          const double nub = rdx * (y0 - a2y) - rdy * (x0 - a2x);
+          // cheap conservative prefilter (no division): clearly outside [0,1] -> next edge; the reference's exact
+          // division test decides everything that survives
+          const double ad = fabs(denom), sa = (denom > 0.0) ? nua : -nua, sb = (denom > 0.0) ? nub : -nub;
+          const double slack = ad * 1e-12;
+          if (sa < -slack || sb < -slack || sa > ad + slack || sb > ad + slack) continue;
+          const double ua = nua / denom;
+          const double ub = nub / denom;
           if (ua >= 0.0 && ua <= 1.0 && ub >= 0.0 && ub <= 1.0) {
             const double qx = x0 + ua * rdx, qy = y0 + ua * rdy;
             const double dd = sqrt((qx - x0) * (qx - x0) + (qy - y0) * (qy - y0));
@@ -102,22 +134,25 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
 
   // ---- 2. DBSCAN ------------------------------------------------------------------------------------
   const double eps2 = eps * eps;
+  unsigned long long vmask[WORDS];                  // which readings exist, one ballot per 64 rays
+#pragma unroll
+  for (int w = 0; w < WORDS; ++w) vmask[w] = __ballot(comp_[w * 64 + lane] >= 0);
   for (int i = lane; i < RMAX; i += 64) {
     int cnt = 0;
     const bool vi = comp_[i] >= 0;
     const double xi = px_[i], yi = py_[i];
+#pragma unroll
     for (int w = 0; w < WORDS; ++w) {
+      // counted, unrolled sweep over all 64 slots of the word (loads pipeline; absent readings are masked after)
       unsigned long long bits = 0ull;
-      if (vi) {
-        for (int k = 0; k < 64; ++k) {
-          const int j = w * 64 + k;
-          if (comp_[j] >= 0) {
+#pragma unroll 16
+      for (int k = 0; k < 64; ++k) {
 #pragma clang fp contract(off)
-            const double dx = xi - px_[j], dy = yi - py_[j];
-            if (dx * dx + dy * dy <= eps2) { bits |= 1ull << k; ++cnt; }
-          }
-        }
+        const double dx = xi - px_[w * 64 + k], dy = yi - py_[w * 64 + k];
+        bits |= (unsigned long long)(dx * dx + dy * dy <= eps2) << k;
       }
+      bits = vi ? (bits & vmask[w]) : 0ull;
+      cnt += __popcll(bits);
       nb_[i][w] = bits;
     }
     root_[i] = (vi && cnt >= min_samples) ? i : NO_ROOT;      // core points start as their own root
