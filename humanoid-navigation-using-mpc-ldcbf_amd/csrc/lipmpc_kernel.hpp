@@ -9,7 +9,10 @@
 //   LDCBF rows of stage a+1: obstacle j on lane c = j & 1.
 // Rows are generated, never stored: G q, G^T w and K = 2I + G^T D G are applied through the
 // problem's structure (rotation blocks, the alternating-sum velocity map, per-stage 2x2 LDCBF
-// blocks), so a problem's live state is n + ~2.5 m doubles in registers.
+// blocks), so a problem's live state is n + ~2.5 m doubles in registers.  For large obstacle sets
+// (more than 5 LDCBF rows per lane) those rows are STREAMED instead: (s, z) per row in LDS, everything
+// else recomputed in each pass (step_body, STREAM).  Two kernels share the body: plan_step_kernel
+// (one step for B problems) and rollout_kernel (the whole closed loop per robot, one launch).
 //
 // Reference semantics followed (HumanoidNavigation/...):
 //   theta/omega            MPC/HumanoidMpc.py:137-160
@@ -37,7 +40,7 @@ constexpr double IPM_S_FLOOR = 0.1;
 constexpr double IPM_Z0 = 30.0;
 constexpr double IPM_STEP_FRAC = 0.995;
 constexpr double IPM_Z_DIVERGE = 1e13;
-constexpr double IPM_STALL_TOL = 1e-6;   // Cholesky breakdown below this (r_p, mu) counts as converged
+constexpr double IPM_STALL_TOL = 1e-6;   // factorisation breakdown below this (r_p, mu) counts as converged
 constexpr double FIN_RHO = 1e10;
 constexpr double FIN_EPS = 1e-9;
 constexpr int FIN_ROUNDS = 10;
@@ -405,7 +408,7 @@ __device__ __forceinline__ StepOut step_body(
     return var_on ? res : 0.0;
   };
 
-  // ---- K = 2I + G^T D G (lane = row), Cholesky, solves ----------------------------------------
+  // ---- K = 2I + G^T D G (lane = row), square-root-free factorisation, solves -----------------------
   double Krow[NV];
   double eqm[NMAX];                      // eqm[b] = 1 if this lane's stage is b
 #pragma unroll
