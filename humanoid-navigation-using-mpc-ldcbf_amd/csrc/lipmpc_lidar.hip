@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
     double* __restrict__ obs_xy, int32_t* __restrict__ obs_nv, int32_t* __restrict__ n_inferred,
     int32_t* __restrict__ overflow, double* __restrict__ hits_out, int32_t* __restrict__ labels_out) {
   __shared__ double px_[RMAX], py_[RMAX];
-  __shared__ int comp_[RMAX];                    // -1 = no reading; core: component root; else NO_ROOT
+  __shared__ __attribute__((aligned(16))) int comp_[RMAX];                    // -1 = no reading; core: component root; else NO_ROOT
   __shared__ int root_[RMAX];                    // cluster root of every reading (NO_ROOT = noise)
   __shared__ unsigned long long nb_[RMAX][WORDS];
   __shared__ int roots_[64];
@@ -160,28 +160,47 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
   __syncthreads();
   for (int i = lane; i < RMAX; i += 64) if (comp_[i] >= 0) comp_[i] = root_[i];
   __syncthreads();
-  // connected components of the core points: min over core neighbours, then pointer jumping, until stable
-  for (int sweep = 0; sweep < RMAX; ++sweep) {
+  // connected components of the core points (hook: min over core neighbours; then pointer jumping to the root;
+  // repeat until a hook round changes nothing — a handful of rounds instead of one per hop of the longest chain)
+  unsigned long long cmask[WORDS];
+#pragma unroll
+  for (int w = 0; w < WORDS; ++w) { const int cj = comp_[w * 64 + lane]; cmask[w] = __ballot(cj >= 0 && cj != NO_ROOT); }
+  for (int round = 0; round < RMAX; ++round) {
     bool changed = false;
     for (int i = lane; i < RMAX; i += 64) {
       const int ci = comp_[i];
+      bool mine = false;
       if (ci >= 0 && ci != NO_ROOT) {
-        int m = ci;
-        for (int w = 0; w < WORDS; ++w) {
-          unsigned long long bits = nb_[i][w];
-          while (bits) {
-            const int k = __ffsll((long long)bits) - 1;
-            bits &= bits - 1;
-            const int cj = comp_[w * 64 + k];
-            if (cj != NO_ROOT && cj < m) m = cj;
+        mine = true;
+      }
+      // lanes of one pass own rays i = lane + 64 k: their neighbours sit in the same few words, so a word is
+      // swept by the whole wave with independent (pipelined, broadcast) LDS reads or skipped by the whole wave
+      int m = mine ? ci : NO_ROOT;
+#pragma unroll
+      for (int w = 0; w < WORDS; ++w) {
+        const unsigned long long bits = mine ? (nb_[i][w] & cmask[w]) : 0ull;
+        if (__any(bits != 0ull)) {
+#pragma unroll 4
+          for (int k4 = 0; k4 < 16; ++k4) {
+            const int4 c4 = *reinterpret_cast<const int4*>(&comp_[w * 64 + k4 * 4]);
+            const unsigned nib = (unsigned)(bits >> (k4 * 4)) & 0xfu;
+            m = (nib & 1u) ? min(m, c4.x) : m;
+            m = (nib & 2u) ? min(m, c4.y) : m;
+            m = (nib & 4u) ? min(m, c4.z) : m;
+            m = (nib & 8u) ? min(m, c4.w) : m;
           }
         }
-        const int mm = comp_[m];                          // pointer jump (m is a core index)
-        if (mm < m) m = mm;
-        if (m < ci) { comp_[i] = m; changed = true; }
       }
+      if (mine && m < ci) { comp_[i] = m; changed = true; }
     }
     __syncthreads();
+    for (int jump = 0; jump < 4; ++jump) {
+      for (int i = lane; i < RMAX; i += 64) {
+        const int ci = comp_[i];
+        if (ci >= 0 && ci != NO_ROOT) { const int cc = comp_[ci]; if (cc < ci) comp_[i] = cc; }
+      }
+      __syncthreads();
+    }
     if (!__any(changed)) break;
   }
   // cluster root of every reading: own component for cores, smallest neighbouring core component for the rest
