@@ -11,6 +11,13 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # build what is missing (normally __graft_entry__.build() has run already; hipcc cross-compiles without a GPU)
+    import subprocess
+    pkg = os.path.join(ROOT, "humanoid-navigation-using-mpc-ldcbf_amd")
+    if not os.path.exists(os.path.join(pkg, "liblipmpc.so")):
+        subprocess.check_call(["make", "-C", os.path.join(pkg, "csrc"), "-j", "8"])
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liblipmpc_oracle.so")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
 
 
 @pytest.fixture(scope="session")
