@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--horizon", type=int, default=8)
     ap.add_argument("--obstacles", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--all-configs", action="store_true",
+                    help="also time BASELINE configs 4 (N=16, 50 obstacles) and 5 (LiDAR front end) as extras")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,6 +151,8 @@ def main():
         }
         if world == 1:
             res["rollout"] = rollout_throughput(lipmpc, walker, obs_xy, obs_nv, goal, delta, dev)
+        if world == 1 and args.all_configs:
+            res["other_configs"] = other_configs(lipmpc, synth, dev)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(P, state, goal, foot, obs_xy, obs_nv, delta, out)
         print(json.dumps(res))
@@ -175,6 +179,56 @@ def rollout_throughput(lipmpc, walker, obs_xy, obs_nv, goal, delta, dev, k_max=4
     steps = int(ro["n_steps"].sum().item())
     return {"solves_per_s": steps / (ms * 1e-3), "ms": ms, "robots": B, "k_max": k_max, "mpc_steps_solved": steps,
             "mean_iters_per_step": float(ro["total_iters"].sum().item()) / max(steps, 1)}
+
+
+def _time_ms(fn, reps=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def other_configs(lipmpc, synth, dev):
+    """Extras (never `value`): BASELINE config 4 and config 5 on one GPU, smaller synthetic batches so the run stays short."""
+    out = {}
+    # config 4: N=16, 50 obstacles (streamed LDCBF rows, 32 lanes per problem)
+    B, N, n_obs = 1024, 16, 50
+    xy, nv = synth.synthetic_fields(B, n_obs, 0.5, 15.5, (0.0, 0.0), (16.0, 16.0), seed=77)
+    oxy, onv = torch.as_tensor(xy, device=dev), torch.as_tensor(nv, device=dev)
+    goal = torch.tensor([[16.0, 16.0]], dtype=torch.float64, device=dev).repeat(B, 1).contiguous()
+    walker = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5, flags=lipmpc.FLAG_INTERIOR), dev.index)
+    solver = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5), dev.index)
+    state, foot = synth.walk_states(walker, oxy, onv, goal, 20, seed=5)
+    o = solver.alloc_outputs(B)
+    ms = _time_ms(lambda: solver.plan_step_batch(state, goal, foot, oxy, onv, None, out=o))
+    st = o["status"].cpu().numpy()
+    out["config4_N16_50obs"] = {"batch": B, "ms_per_step": ms, "solves_per_s": B / ms * 1e3,
+                                "mean_iters": float(o["iters"].double().mean()),
+                                "status_hist": {str(k): int(v) for k, v in zip(*np.unique(st, return_counts=True))}}
+    # config 5: LiDAR scan -> clusters -> hulls -> step, 4096 robots on one CROWDED-style map (20 obstacles)
+    B, N = 4096, 3
+    exy, env = synth.synthetic_fields(1, 20, -1.0, 6.0, (-5.0, -5.0), (50.0, 50.0), seed=9, delta=0.6)
+    rings = [exy[0, j, : env[0, j]] for j in range(20) if env[0, j] > 0]
+    sensor = lipmpc.LidarSensor(rings, lidar_range=1.5, resolution=360, n_obs_max=12, v_max=32, device=dev.index)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    pos = torch.rand((B, 2), dtype=torch.float64, device=dev, generator=gen) * 7.0 - 1.0
+    state = torch.zeros((B, 5), dtype=torch.float64, device=dev); state[:, 0] = pos[:, 0]; state[:, 2] = pos[:, 1]
+    noise = 0.01 * torch.randn((B, 360, 2), dtype=torch.float64, device=dev, generator=gen)
+    goal = torch.tensor([[5.0, 5.0]], dtype=torch.float64, device=dev).repeat(B, 1).contiguous()
+    foot = torch.ones((B,), dtype=torch.int8, device=dev)
+    solver = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=12, v_max=32), dev.index)
+    o = solver.alloc_outputs(B)
+    ms_scan = _time_ms(lambda: sensor.sense(state, noise))
+    sen = sensor.sense(state, noise)
+    ms_step = _time_ms(lambda: solver.plan_step_batch(state, goal, foot, sen["obs_xy"], sen["obs_nv"], None, out=o))
+    out["config5_lidar"] = {"batch": B, "ms_scan": ms_scan, "ms_step": ms_step,
+                            "robot_steps_per_s": B / (ms_scan + ms_step) * 1e3,
+                            "mean_inferred_obstacles": float(sen["n_inferred"].double().mean()),
+                            "overflow": int(sen["overflow"].sum())}
+    return out
 
 
 def cpu_baseline(P, state, goal, foot, obs_xy, obs_nv, delta, out):
