@@ -16,7 +16,7 @@ class LipmpcParamsC(C.Structure):
         ("l_max", C.c_double * 2), ("l_min", C.c_double * 2), ("v_min", C.c_double * 2),
         ("v_max_xy", C.c_double * 2),
         ("omega_max", C.c_double), ("ell", C.c_double), ("sampling_time", C.c_double),
-        ("tol", C.c_double), ("k0_tol", C.c_double),
+        ("tol", C.c_double), ("tol_interior", C.c_double), ("k0_tol", C.c_double),
     ]
 
 

@@ -47,7 +47,7 @@ int lipmpc_default_params(lipmpc_params* p) {
   p->l_max[0] = 0.10; p->l_max[1] = 0.10; p->l_min[0] = -0.1; p->l_min[1] = -0.1;
   p->v_min[0] = -0.1; p->v_min[1] = 0.1; p->v_max_xy[0] = 0.8; p->v_max_xy[1] = 0.4;
   p->omega_max = 0.156 * M_PI; p->ell = 0.05; p->sampling_time = 0.4;
-  p->tol = 1e-9; p->k0_tol = 1e-5;
+  p->tol = 1e-11; p->tol_interior = 1e-9; p->k0_tol = 1e-5;
   return LIPMPC_OK;
 }
 
@@ -57,7 +57,7 @@ int64_t lipmpc_active_words(const lipmpc_params* p) { return p ? (lipmpc_num_row
 int lipmpc_create(const lipmpc_params* p, int device, lipmpc_handle** out) {
   if (!p || !out) return LIPMPC_E_ARG;
   if (p->N < 1 || p->N > 16 || p->n_obs_max < 0 || p->n_obs_max > 50 || p->v_max < 3 || p->v_max > 32 ||
-      p->max_iter < 1 || !(p->tol > 0.0) || !(p->dt > 0.0) || !(p->h_com > 0.0) || !(p->g > 0.0))
+      p->max_iter < 1 || !(p->tol > 0.0) || !(p->tol_interior > 0.0) || !(p->dt > 0.0) || !(p->h_com > 0.0) || !(p->g > 0.0))
     return LIPMPC_E_UNSUPPORTED;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return LIPMPC_E_HIP;
@@ -76,7 +76,7 @@ int lipmpc_create(const lipmpc_params* p, int device, lipmpc_handle** out) {
   k.beta_sh = beta * sh;
   for (int i = 0; i < 2; ++i) { k.l_max[i] = p->l_max[i]; k.l_min[i] = p->l_min[i]; k.v_min[i] = p->v_min[i]; k.v_max[i] = p->v_max_xy[i]; }
   k.alpha_over_pi = p->alpha / M_PI; k.omega_max = p->omega_max; k.ell = p->ell; k.tau = p->sampling_time;
-  k.tol = p->tol; k.k0_tol = p->k0_tol;
+  k.tol = (p->flags & LIPMPC_FLAG_INTERIOR) ? p->tol_interior : p->tol; k.k0_tol = p->k0_tol;
   *out = h;
   return LIPMPC_OK;
 }

@@ -775,7 +775,7 @@ __device__ __forceinline__ StepOut step_body(
   const unsigned fbits = abits;          // fallback working set of an uncertified finish
   const double margin = gmin<G>(marg_l);
   const double mu_fin = gsum<G>(mufin_l) / fmax(m_rows, 1.0);
-  double diag_rounds = 0.0, diag_eres = 0.0;
+  double diag_rounds = 0.0, diag_eres = 0.0, diag_cert = 0.0;
 
   // ---- certified active-set finish --------------------------------------------------------------
   const bool ipm_ok = (status == LIPMPC_STATUS_SOLVED) && (m_rows > 0.0);
@@ -912,6 +912,7 @@ __device__ __forceinline__ StepOut step_body(
         } else {
           fin_done = true;
           certified = fok && (eres <= FIN_EPS) && (qabs < 1e300);
+          diag_cert = fmin(ymin, smin);      // how decisively the certificate holds (weakly active rows -> ~0)
         }
         diag_rounds = rnd + 1;
         diag_eres = eres;
@@ -973,7 +974,7 @@ __device__ __forceinline__ StepOut step_body(
       obj_out[pb] = have_sol ? objv : nanv;
       status_out[pb] = status;
       iters_out[pb] = iters;
-      if (diag) { diag[pb * 4 + 0] = diag_rounds; diag[pb * 4 + 1] = diag_eres; diag[pb * 4 + 2] = margin; diag[pb * 4 + 3] = mu_fin; }
+      if (diag) { diag[pb * 4 + 0] = diag_rounds; diag[pb * 4 + 1] = diag_eres; diag[pb * 4 + 2] = margin; diag[pb * 4 + 3] = diag_cert; }
     }
     for (int wi = lane; wi < P.words; wi += G) active_out[pb * P.words + wi] = lds_act[grp][wi];
   }

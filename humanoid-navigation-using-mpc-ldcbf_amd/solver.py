@@ -35,14 +35,15 @@ class LipMpcParams:
     omega_max: float = 0.156 * math.pi
     ell: float = 0.05
     sampling_time: float = 0.4
-    tol: float = 1e-9
+    tol: float = 1e-11
+    tol_interior: float = 1e-9
     k0_tol: float = 1e-5
 
     def to_c(self):
         p = _lib.LipmpcParamsC()
         for f in ("N", "n_obs_max", "v_max", "max_iter", "flags"):
             setattr(p, f, int(getattr(self, f)))
-        for f in ("dt", "g", "h_com", "alpha", "omega_max", "ell", "sampling_time", "tol", "k0_tol"):
+        for f in ("dt", "g", "h_com", "alpha", "omega_max", "ell", "sampling_time", "tol", "tol_interior", "k0_tol"):
             setattr(p, f, float(getattr(self, f)))
         for f in ("l_max", "l_min", "v_min", "v_max_xy"):
             v = getattr(self, f)

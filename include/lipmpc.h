@@ -67,13 +67,16 @@ typedef struct lipmpc_params {
   double omega_max;     /* 0.156*pi           HumanoidMpc.py:21 */
   double ell;           /* 0.05               HumanoidMpc.py:200 */
   double sampling_time; /* theta update step  HumanoidMpc.py:159 */
-  double tol;           /* interior-point stop: max|r_p| <= tol and mu <= tol */
+  double tol;           /* interior-point stop (exact path): max|r_p| <= tol and mu <= tol */
+  double tol_interior;  /* the same for LIPMPC_FLAG_INTERIOR: sets how far inside its constraints the returned iterate
+                           stays (the reference's IPOPT stops at 1e-5); too tight and a closed loop lands on LDCBF
+                           boundaries where the next eta = (x-c)/|x-c| is 0/0 */
   double k0_tol;        /* tolerated violation of the constant k=0 LDCBF rows (IPOPT constr_viol_tol, HumanoidMpc.py:99) */
 } lipmpc_params;
 
 typedef struct lipmpc_handle lipmpc_handle;
 
-/* fills *p with the reference's config.yml values, N=3, n_obs_max=0, v_max=5, tol=1e-9 */
+/* fills *p with the reference's config.yml values, N=3, n_obs_max=0, v_max=5, tol=1e-11, tol_interior=1e-9 */
 int lipmpc_default_params(lipmpc_params* p);
 
 int lipmpc_create(const lipmpc_params* p, int device, lipmpc_handle** out);
@@ -99,7 +102,8 @@ int64_t lipmpc_active_words(const lipmpc_params* p);
  *  bounds [B,4] or NULL: per-problem (V_MAX_x, V_MAX_y, ALPHA, OMEGA_MAX) replacing the handle's values —
  *         the knobs the reference's bounds_tuning sweep mutates in `conf` (bounds_tuning.py:17-26)
  *  diag   [B,4] or NULL: (active-set rounds used, final equality residual of the finish,
- *         identification margin min_i |log(z_i/s_i)| of the interior-point phase, final mu)
+ *         identification margin min_i |log(z_i/(1e5 s_i))| of the interior-point phase, certificate margin =
+ *         min(smallest active multiplier, smallest inactive slack): ~0 flags a weakly determined active set)
  */
 int lipmpc_plan_step_batch(lipmpc_handle* h, int64_t B,
                            const double* state, const double* goal, const int8_t* first_foot,

@@ -279,6 +279,7 @@ static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, cons
   for (int i = 0; i < m; ++i) { s[i] = fmax(h[i] - t[i], IPM_S_FLOOR); z[i] = IPM_Z0; }
   int status = LIPMPC_STATUS_MAX_ITER, it = 0;
   double mu = 0.0;
+  const double tol = (P->flags & LIPMPC_FLAG_INTERIOR) ? P->tol_interior : P->tol;
   for (it = 0; it <= P->max_iter; ++it) {
     mat_vec(G, q, m, n, t);
     double rpmax = 0.0, zmax = 0.0, qmax = 0.0;
@@ -291,7 +292,7 @@ static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, cons
     }
     mu /= m;
     for (int i = 0; i < n; ++i) qmax = fmax(qmax, fabs(q[i]));
-    if (rpmax <= P->tol && mu <= P->tol) { status = LIPMPC_STATUS_SOLVED; break; }
+    if (rpmax <= tol && mu <= tol) { status = LIPMPC_STATUS_SOLVED; break; }
     if (it == P->max_iter) break;
     if (!(zmax < IPM_Z_DIVERGE) || !(qmax < 1e300)) { status = LIPMPC_STATUS_INFEASIBLE; break; }
     for (int i = 0; i < m; ++i) d[i] = z[i] / s[i];
@@ -329,7 +330,7 @@ static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, cons
   if (status != LIPMPC_STATUS_SOLVED) return;
   double margin = INFINITY;
   for (int i = 0; i < m; ++i) margin = fmin(margin, fabs(log(z[i] / (FIN_IDENT * s[i]))));
-  if (diag) { diag[2] = margin; diag[3] = mu; }
+  if (diag) { diag[2] = margin; diag[3] = 0.0; }
 
   /* ---- certified active-set finish ------------------------------------------------------------- */
   int* act = W->act;
@@ -376,6 +377,7 @@ static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, cons
       double qmax = 0.0;
       for (int i = 0; i < n; ++i) qmax = fmax(qmax, fabs(qf[i]));
       certified = fok && eres <= FIN_EPS && qmax < 1e300;
+      if (diag) diag[3] = fmin(ymin, smin);
       break;
     }
     if (diag) { diag[0] = rounds; diag[1] = eres; }

@@ -59,7 +59,8 @@ class Params:
     ell: float = 0.05
     sampling_time: float = 0.4
     # solver knobs (build-defined)
-    tol: float = 1e-9
+    tol: float = 1e-11
+    tol_interior: float = 1e-9      # stop tolerance of the interior (non-finished) mode, see include/lipmpc.h
     max_iter: int = 60
     k0_tol: float = 1e-5            # tolerated violation of the constant k=0 LDCBF rows
                                     # (= the reference's IPOPT constr_viol_tol, HumanoidMpc.py:99)
@@ -330,6 +331,7 @@ class QPResult:
     active: np.ndarray = field(default=None)
     margin: float = math.inf
     rounds: int = 0
+    cert_margin: float = 0.0     # min(smallest active multiplier, smallest inactive slack) of the certificate
 
 
 # solver constants shared (by value) with oracle/lipmpc_oracle.c and the HIP kernel
@@ -346,7 +348,7 @@ FIN_INNER = 6          # max multiplier iterations per equality solve
 FIN_INNER_TOL = 1e-11
 
 
-def solve_qp_ipm(G, h, g, q0, tol=1e-9, max_iter=60):
+def solve_qp_ipm(G, h, g, q0, tol=1e-11, max_iter=60):
     """min |q-g|^2 s.t. G q <= h by Mehrotra predictor-corrector on the normal equations
     K = 2I + G^T diag(z/s) G (slack form G q + s = h, s,z > 0).  Start: q0 (the caller passes
     "stand still", p_k = p_0), s = max(h - G q0, 0.1), z = 30.  Stop when max|r_p| <= tol and
@@ -468,12 +470,14 @@ def finish_active_set(G, h, g, res: QPResult):
             A[smin_i] = True
             continue
         if eres <= FIN_EPS and np.all(np.isfinite(q)):
-            return q, yf, slack, A, rnd, True
+            cert = min(float(np.min(yf[A])) if A.any() else math.inf,
+                       float(np.min(slack[~A & nz])) if (~A & nz).any() else math.inf)
+            return q, yf, slack, A, rnd, cert
         break
-    return q, yf, None, A, FIN_ROUNDS, False
+    return q, yf, None, A, FIN_ROUNDS, None
 
 
-def solve_qp_exact(G, h, g, q0, tol=1e-9, max_iter=60):
+def solve_qp_exact(G, h, g, q0, tol=1e-11, max_iter=60):
     """IPM, then the certified active-set finish.  status 4 = IPM converged but the finish did
     not certify within its round budget (the IPM point is returned)."""
     res = solve_qp_ipm(G, h, g, q0, tol=tol, max_iter=max_iter)
@@ -484,9 +488,10 @@ def solve_qp_exact(G, h, g, q0, tol=1e-9, max_iter=60):
     with np.errstate(divide="ignore"):
         lr = np.abs(np.log(res.z[nz] / (FIN_IDENT * res.s[nz])))
     res.margin = float(np.min(lr)) if lr.size else math.inf
-    q, y, slack, A, rounds, ok = finish_active_set(G, h, g, res)
+    q, y, slack, A, rounds, cert = finish_active_set(G, h, g, res)
     res.rounds = rounds
-    if ok:
+    res.cert_margin = cert if cert is not None else 0.0
+    if cert is not None:
         res.q, res.z, res.s, res.active = q, y, np.maximum(slack, 0.0), A
     else:
         res.status = STATUS_UNCERTIFIED
@@ -597,7 +602,7 @@ def plan_step(state, goal, first_foot, obstacles, delta, P: Params, exact=True):
     Gs, hs = G[keep], h[keep]
     q0 = np.tile([x0[0], x0[2]], N)
     res = solve_qp_exact(Gs, hs, g, q0, tol=P.tol, max_iter=P.max_iter) if exact else \
-        solve_qp_ipm(Gs, hs, g, q0, tol=P.tol, max_iter=P.max_iter)
+        solve_qp_ipm(Gs, hs, g, q0, tol=P.tol_interior, max_iter=P.max_iter)
     out["status"], out["iters"], out["rounds"] = res.status, res.iters, res.rounds
     if res.status not in (STATUS_SOLVED, STATUS_UNCERTIFIED):
         return out
@@ -608,6 +613,7 @@ def plan_step(state, goal, first_foot, obstacles, delta, P: Params, exact=True):
     if res.active is not None:
         out["active"][keep] = res.active
     out["margin"] = res.margin
+    out["cert_margin"] = res.cert_margin
     out["q"] = res.q
     return out
 

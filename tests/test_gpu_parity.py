@@ -58,7 +58,9 @@ def compare(problems, res, N, exact=True, tol_u=1e-5):
         assert abs(res["obj"][b] - r["obj"]) < 1e-6 * max(1.0, abs(r["obj"]))
         it_diff = max(it_diff, abs(int(res["iters"][b]) - r["iters"]))
         if exact:
-            if r["margin"] < 0.5:
+            # weakly determined active sets (identification margin of the IPM, or a certificate that holds with
+            # a multiplier / slack within 1e-6 of zero) are excluded from the bit-exact comparison and counted
+            if r["margin"] < 0.5 or r.get("cert_margin", 1.0) < 1e-6 or res["diag"][b][3] < 1e-6:
                 n_weak += 1
             else:
                 n_act_cmp += 1
@@ -219,7 +221,7 @@ def test_full_size_batch_against_c_oracle():
     assert np.max(np.abs(g["U"][ok] - ref["U"][ok])) < 1e-5        # north_star tolerance (observed ~1e-8)
     assert np.max(np.abs(g["X"][ok] - ref["X"][ok])) < 1e-5
     assert np.max(np.abs(g["theta"] - ref["theta"])) < 1e-12
-    strong = ok & (g["diag"][:, 2] >= 0.5) & (ref["diag"][:, 2] >= 0.5)
+    strong = ok & (g["diag"][:, 2] >= 0.5) & (ref["diag"][:, 2] >= 0.5) & (g["diag"][:, 3] >= 1e-6) & (ref["diag"][:, 3] >= 1e-6)
     act_g = lipmpc.unpack_active(g["active"], P.num_rows)
     act_r = lipmpc.unpack_active(ref["active"], P.num_rows)
     assert strong.sum() > 0.8 * B
