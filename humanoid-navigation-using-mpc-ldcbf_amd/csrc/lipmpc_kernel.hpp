@@ -62,7 +62,7 @@ struct KArgs {
 //   broadcast of lane j      v_mov_b64_dpp row_newbcast:j
 //   xor 1 / 2                quad_perm, xor 4: row_shl:4 / row_shr:4 under bank masks, xor 8: row_ror:8
 //   shift by 2/4/8 stages    row_shr / row_shl with zero fill
-// G = 32 (two rows): in-row steps by DPP, cross-row steps through ds_bpermute.
+// G = 32 (two rows): in-row steps by DPP, cross-row steps by v_permlane16_swap_b32 (no LDS crossbar either).
 // ------------------------------------------------------------------------------------------
 template <int I, int E, class F> __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < E) {
@@ -88,23 +88,64 @@ template <int M, class T> __device__ __forceinline__ T row_xor(T x) {
     return __builtin_amdgcn_update_dpp(r, x, 0x114, 0xf, 0xA, false);     // banks 1,3 <- lane-4
   } else return dpp0<0x128>(x);                               // row_ror:8
 }
+// G = 32: a group is two DPP rows.  v_permlane16_swap_b32 (gfx950) with both operands = v returns
+// {even row's v replicated over the row pair, odd row's v replicated}: the cross-row half of every exchange,
+// as a VALU instruction (no LDS crossbar).
+template <class T> __device__ __forceinline__ void rowpair(T v, T& even_rep, T& odd_rep) {
+  if constexpr (sizeof(T) == 8) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    even_rep = __builtin_bit_cast(T, ((unsigned long long)b[0] << 32) | a[0]);
+    odd_rep = __builtin_bit_cast(T, ((unsigned long long)b[1] << 32) | a[1]);
+  } else {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const unsigned a0 = a[0], a1 = a[1];        // by value: __builtin_bit_cast of a vector-element lvalue reads element 0
+    even_rep = __builtin_bit_cast(T, a0);
+    odd_rep = __builtin_bit_cast(T, a1);
+  }
+}
+// the value the lane 16 positions away holds (row swap inside a 32-lane group)
+template <class T> __device__ __forceinline__ T rowswap(T v) {
+  T e, o;
+  rowpair(v, e, o);
+  const T r = (threadIdx.x & 16) ? e : o;
+  return r;
+}
 template <int G, int M, class T> __device__ __forceinline__ T gxor(T x) {
   if constexpr (M < 16) return row_xor<M>(x);
-  else return __shfl_xor(x, M, G);
+  else return rowswap(x);
 }
 // value held by lane J of the group, J a compile-time constant
 template <int G, int J> __device__ __forceinline__ double gbcast(double x) {
-  if constexpr (G == 16) return __builtin_amdgcn_mov_dpp(x, 0x150 + J, 0xf, 0xf, false);
-  else return __shfl(x, J, G);
+  const double t = __builtin_amdgcn_mov_dpp(x, 0x150 + (J & 15), 0xf, 0xf, false);   // row_newbcast inside each row
+  if constexpr (G == 16) return t;
+  else {
+    double e, o;
+    rowpair(t, e, o);
+    return (J < 16) ? e : o;
+  }
 }
 // value of the lane D below / above (0 outside the group)
 template <int G, int D> __device__ __forceinline__ double gup(double x, int lane) {
   if constexpr (G == 16) return dpp0<0x110 + D>(x);
-  else { double t = __shfl_up(x, D, G); return (lane >= D) ? t : 0.0; }
+  else if constexpr (D == 16) { const double w = rowswap(x); return (lane & 16) ? w : 0.0; }
+  else {
+    const double t = dpp0<0x120 + D>(x);            // row_ror:D -> t[i] = x[(i - D) mod 16] of the same row
+    const double w = rowswap(t);                     // the other row's rotated copy
+    return ((lane & 15) >= D) ? t : ((lane & 16) ? w : 0.0);
+  }
 }
 template <int G, int D> __device__ __forceinline__ double gdown(double x, int lane) {
   if constexpr (G == 16) return dpp0<0x100 + D>(x);
-  else { double t = __shfl_down(x, D, G); return (lane + D < G) ? t : 0.0; }
+  else if constexpr (D == 16) { const double w = rowswap(x); return (lane & 16) ? 0.0 : w; }
+  else {
+    const double t = dpp0<0x120 + (16 - D)>(x);     // row_ror:(16-D) -> t[i] = x[(i + D) mod 16]
+    const double w = rowswap(t);
+    return ((lane & 15) + D < 16) ? t : ((lane & 16) ? 0.0 : w);
+  }
 }
 
 template <int G> __device__ __forceinline__ double gsum(double x) {
