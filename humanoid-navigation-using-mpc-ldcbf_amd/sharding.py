@@ -19,7 +19,7 @@ def gather_counters(elapsed_s: float, n_problems: int, n_solved: int, device=Non
     """All ranks -> (max elapsed, total problems, total solved, per-rank table [world,3])."""
     rec = torch.tensor([float(elapsed_s), float(n_problems), float(n_solved)], dtype=torch.float64,
                        device=device if device is not None else "cpu")
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         parts = [torch.zeros_like(rec) for _ in range(dist.get_world_size())]
         dist.all_gather(parts, rec)
         table = torch.stack(parts).cpu()
