@@ -2,5 +2,5 @@
 solve of salvatore373/Humanoid-Navigation-using-MPC-LDCBF, HumanoidNavigation/MPC)."""
 from .solver import (BatchedLipMpc, LipMpcParams, pack_rings, unpack_active, FLAG_INTERIOR,  # noqa: F401
                      STATUS_SOLVED, STATUS_MAX_ITER, STATUS_INFEASIBLE, STATUS_DEGENERATE, STATUS_UNCERTIFIED)
-from .compat import HumanoidMPC, HumanoidMPCCustomLCBF  # noqa: F401
+from .compat import HumanoidMPC, HumanoidMPCCustomLCBF, HumanoidMPCWithRRT  # noqa: F401
 from .lidar import LidarSensor, HumanoidMPCUnknownEnvironment, ray_table  # noqa: F401

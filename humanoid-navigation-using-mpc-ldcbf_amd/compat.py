@@ -186,3 +186,55 @@ class HumanoidMPCCustomLCBF(HumanoidMPC):
         self.distance_from_obstacles = distance_from_obstacles
         super().__init__(goal, obstacles, N_horizon, N_mpc_timesteps, sampling_time,
                          np.zeros(5) if init_state is None else init_state, start_with_right_foot, verbosity, **kw)
+
+
+class HumanoidMPCWithRRT(HumanoidMPC):
+    """Reach the goal through a sequence of sub-goals (HumanoidMPCVariants/HumanoidMPCWithRRT.py:15-183).
+
+    The reference obtains the sub-goals from ``rrtplanner.RRTStar`` on an occupancy grid (:98-138) — sequential,
+    CPU-side planning that is outside the accelerated path (and ``rrtplanner`` is not installed here).  What belongs
+    to the MPC path is the hand-off (:155-181), mirrored exactly: one fresh ``HumanoidMPC`` per sub-goal with the
+    parent's horizon / sample count / sampling time / first foot, started from the last state of the previous run,
+    X_pred / U_pred concatenated as they come (the hand-off state appears twice, as there).  Like the reference
+    (:155) the first run starts from (0, 0, 0, 0, 0) whatever ``init_state`` says unless ``honour_init_state=True``.
+
+    Sub-goals come from ``sub_goals`` ([S,2], the last one normally the goal), or from ``planner(self) -> [S,2]``.
+    With neither, ``run_simulation`` raises ImportError: there is no built-in planner.
+    """
+
+    def __init__(self, goal, obstacles, N_horizon=3, N_mpc_timesteps=100, sampling_time=1e-3,
+                 init_state: Union[np.ndarray, tuple] = np.array([0, 0, 0, 0, 0]),
+                 start_with_right_foot: bool = True, verbosity: int = 1, *, sub_goals=None, planner=None,
+                 honour_init_state: bool = False, **kw):
+        super().__init__(goal, obstacles, N_horizon, N_mpc_timesteps, sampling_time, init_state,
+                         start_with_right_foot, verbosity, **kw)
+        self.sub_goals = None if sub_goals is None else np.asarray(sub_goals, float).reshape(-1, 2)
+        self.planner = planner
+        self.honour_init_state = honour_init_state
+        self._kw = kw
+
+    def run_simulation(self, path_to_gif: str = None, make_fast_plot: bool = True, plot_animation: bool = False,
+                       fill_animator: bool = True, initial_animator=None, visualize_rrt_path: bool = False,
+                       path_to_rrt_pdf: str = None):
+        if self.sub_goals is not None:
+            sub_goals = self.sub_goals
+        elif self.planner is not None:
+            sub_goals = np.asarray(self.planner(self), float).reshape(-1, 2)
+        else:
+            raise ImportError("HumanoidMPCWithRRT: no planner available (rrtplanner is not part of this library); "
+                              "pass sub_goals=[[x, y], ...] or planner=callable")
+        X_glob, U_glob = None, None
+        start_state = tuple(self.init_state) if self.honour_init_state else (0, 0, 0, 0, 0)
+        animator = initial_animator
+        for sub_goal in sub_goals:
+            cur = HumanoidMPC(goal=sub_goal, init_state=start_state, obstacles=self.obstacles,
+                              N_horizon=self.N_horizon, N_mpc_timesteps=self.N_simul, sampling_time=self.sampling_time,
+                              start_with_right_foot=self.start_with_right_foot, verbosity=self.verbosity, **self._kw)
+            cur.distance_from_obstacles = self.distance_from_obstacles
+            cur._solver = self._solver                       # same obstacle set: keep the handle
+            X, U, animator = cur.run_simulation(path_to_gif, False, False, fill_animator, animator)
+            self._solver, self.last_status = cur._solver, cur.last_status
+            start_state = tuple(X[:, -1])                   # :177
+            X_glob = X if X_glob is None else np.concatenate((X_glob, X), axis=1)      # :179-180
+            U_glob = U if U_glob is None else np.concatenate((U_glob, U), axis=1)
+        return X_glob, U_glob, animator

@@ -171,6 +171,43 @@ class BatchedLipMpc:
         _lib.check(rc, "lipmpc_rollout_batch")
         return out
 
+    def rollout_subgoals(self, state0, sub_goals, n_sub, first_foot, obs_xy=None, obs_nv=None, delta=None, k_max=100,
+                         mpc_step=1, stop_obj=0.05, bounds=None):
+        """Sub-goal sequencing for B robots (the hand-off of HumanoidMPCWithRRT.py:155-181): robot b walks to
+        sub_goals[b, 0], then from where it stopped to sub_goals[b, 1], ... for n_sub[b] segments; every segment is
+        a fresh closed loop (foot schedule restarts at first_foot[b], own k_max budget) kept with the reference's
+        truncation, so a segment that uses all k_max samples hands over its last-but-one state.  A robot whose
+        solve fails stops there.  One rollout launch per segment over the robots still walking.
+        Returns dict(X_pred [B,S,k_max+1,5], U_pred [B,S,k_max,3], n_kept [B,S] kept inputs per segment
+        (kept states = n_kept+1; -1 = segment not run), last_status [B], final_state [B,5])."""
+        B = self._check_inputs(state0, sub_goals[:, 0].contiguous(), first_foot, obs_xy, obs_nv, delta)
+        S = sub_goals.shape[1]
+        dev = self.device
+        out = dict(X_pred=torch.zeros((B, S, k_max + 1, 5), dtype=torch.float64, device=dev),
+                   U_pred=torch.zeros((B, S, k_max, 3), dtype=torch.float64, device=dev),
+                   n_kept=torch.full((B, S), -1, dtype=torch.int32, device=dev),
+                   last_status=torch.zeros((B,), dtype=torch.int32, device=dev),
+                   final_state=state0.clone())
+        alive = torch.ones((B,), dtype=torch.bool, device=dev)
+        sel = lambda t, i: None if t is None else t.index_select(0, i).contiguous()
+        for s in range(S):
+            idx = torch.nonzero(alive & (n_sub.to(dev) > s)).flatten()
+            if idx.numel() == 0:
+                break
+            ro = self.rollout(sel(out["final_state"], idx), sel(sub_goals[:, s], idx), sel(first_foot, idx),
+                              sel(obs_xy, idx), sel(obs_nv, idx), sel(delta, idx), k_max=k_max, mpc_step=mpc_step,
+                              stop_obj=stop_obj, bounds=sel(bounds, idx))
+            n = ro["n_steps"].to(torch.int64)
+            kept = torch.where(n < k_max, n, torch.full_like(n, k_max - 1))        # HumanoidMpc.py:457-459
+            out["X_pred"][idx, s] = ro["X_pred"]
+            out["U_pred"][idx, s] = ro["U_pred"]
+            out["n_kept"][idx, s] = kept.to(torch.int32)
+            out["last_status"][idx] = ro["last_status"]
+            out["final_state"][idx] = ro["X_pred"][torch.arange(idx.numel(), device=dev), kept]
+            ok = (ro["last_status"] == STATUS_SOLVED) | (ro["last_status"] == STATUS_UNCERTIFIED)
+            alive[idx] = ok
+        return out
+
 
 def unpack_active(active_words: np.ndarray, num_rows: int) -> np.ndarray:
     """[B,words] int64/uint64 -> [B,num_rows] bool in canonical row order."""

@@ -191,6 +191,47 @@ def test_compat_class_closed_loop(golden_dir):
     assert np.max(np.abs(X[:, :n] - Xo[:, :n])) < 1e-5
 
 
+def test_subgoal_sequencing_matches_oracle_handoff(golden_dir):
+    """HumanoidMPCWithRRT hand-off (HumanoidMPCWithRRT.py:155-181) with given sub-goals: a fresh closed loop per
+    sub-goal from the previous run's last state, outputs concatenated; against the oracle loop chained the same
+    way, and the batched rollout_subgoals against the class robot by robot (different numbers of sub-goals)."""
+    obs = load_rings(os.path.join(golden_dir, "scenario_circles.npz"))
+    subs = np.array([[1.0, -2.0], [4.0, -2.5], [6.0, -3.0]])
+    kw = dict(N_horizon=3, N_mpc_timesteps=40, sampling_time=0.4)
+    mpc = lipmpc.HumanoidMPCWithRRT(goal=(6, -3), obstacles=obs, init_state=(9, 9, 9, 9, 9), verbosity=0,
+                                    sub_goals=subs, **kw)
+    X, U, _ = mpc.run_simulation(None, make_fast_plot=False, fill_animator=False)
+    Xo, Uo, st = None, None, (0, 0, 0, 0, 0)           # the reference ignores init_state here (:155)
+    lens = []
+    for g in subs:
+        xs, us = O.run_closed_loop(tuple(g), obs, init_state=st, exact=False, **kw)
+        st = tuple(xs[:, -1])
+        lens.append(xs.shape[1])
+        Xo = xs if Xo is None else np.concatenate((Xo, xs), axis=1)
+        Uo = us if Uo is None else np.concatenate((Uo, us), axis=1)
+    assert X.shape == Xo.shape and U.shape == Uo.shape and len(lens) == 3 and min(lens) > 3
+    assert np.max(np.abs(X - Xo)) < 1e-5 and np.max(np.abs(U - Uo)) < 1e-5
+    assert np.hypot(X[0, -1] - 6.0, X[2, -1] + 3.0) < 0.2          # arrived
+    with pytest.raises(ImportError):
+        lipmpc.HumanoidMPCWithRRT(goal=(6, -3), obstacles=obs, verbosity=0, **kw).run_simulation(None)
+    # batched: robot 0 walks all three sub-goals, robot 1 two, robot 2 one
+    P = lipmpc.LipMpcParams(N=3, n_obs_max=len(obs), v_max=max(len(r) for r in obs), flags=lipmpc.FLAG_INTERIOR)
+    sv = lipmpc.BatchedLipMpc(P)
+    xy, nv = lipmpc.pack_rings([obs] * 3, P.n_obs_max, P.v_max)
+    n_sub = torch.tensor([3, 2, 1], dtype=torch.int32)
+    out = sv.rollout_subgoals(_dev(np.zeros((3, 5)), torch.float64), _dev(np.repeat(subs[None], 3, 0), torch.float64),
+                              n_sub, _dev(np.ones(3, np.int8), torch.int8), _dev(xy, torch.float64),
+                              _dev(nv, torch.int32), None, k_max=40, mpc_step=1)
+    torch.cuda.synchronize()
+    nk = out["n_kept"].cpu().numpy()
+    Xb = out["X_pred"].cpu().numpy()
+    assert nk[1, 2] == -1 and nk[2, 1] == -1 and nk[2, 2] == -1
+    for b, ns in enumerate([3, 2, 1]):
+        cat = np.concatenate([Xb[b, s, : nk[b, s] + 1].T for s in range(ns)], axis=1)
+        ref = Xo[:, : sum(lens[:ns])]
+        assert cat.shape == ref.shape and np.max(np.abs(cat - ref)) < 1e-5
+
+
 def test_full_size_batch_against_c_oracle():
     """BASELINE config 2 at full size: B=4096, N=8, 10 obstacles (bench.py's generator and on-device
     walk), every problem compared with the dense C oracle; plus size-independent properties:
