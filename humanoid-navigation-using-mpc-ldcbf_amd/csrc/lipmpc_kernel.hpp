@@ -505,39 +505,111 @@ __device__ __forceinline__ StepOut step_body(
   // Per (j, c) that is one row_newbcast move and one FMA, with f = 0 on lanes <= j instead of
   // predication.  Returns false on a non-positive pivot.
   double ipiv = 0.5;
+  // broadcast inside the lane's own DPP row (16 lanes)
+  auto bc16 = [](auto ic, double x) -> double {
+    return __builtin_amdgcn_mov_dpp(x, 0x150 + decltype(ic)::value, 0xf, 0xf, false);
+  };
   auto factor = [&]() -> bool {
     bool ok = true;
     static_for<0, NV>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      const double pj = gbcast<G, j>(Krow[j]);
-      ok = ok && (pj > 0.0);
-      const double ip = fast_rcp(pj);
-      const double f = (lane > j) ? Krow[j] * ip : 0.0;
-      if (lane == j) ipiv = ip;
-      static_for<j + 1, NV>([&](auto cc_) {
-        constexpr int cc = decltype(cc_)::value;
-        Krow[cc] = fma(-f, gbcast<G, j>(Krow[cc]), Krow[cc]);
-      });
+      if constexpr (G == 16) {
+        const double pj = gbcast<G, j>(Krow[j]);
+        ok = ok && (pj > 0.0);
+        const double ip = fast_rcp(pj);
+        const double f = (lane > j) ? Krow[j] * ip : 0.0;
+        if (lane == j) ipiv = ip;
+        static_for<j + 1, NV>([&](auto cc_) {
+          constexpr int cc = decltype(cc_)::value;
+          Krow[cc] = fma(-f, gbcast<G, j>(Krow[cc]), Krow[cc]);
+        });
+      } else {
+        // Two DPP rows per problem.  Row j of the Schur complement equals its column j, and the column is
+        // lane-distributed (lane cc holds S[cc][j] in Krow[j]): ONE cross-row exchange per step makes both
+        // 16-lane halves of the column visible in every row, after which each needed entry is an in-row broadcast.
+        double cA, cB;                                    // S[0..15][j], S[16..31][j] by local lane position
+        rowpair(Krow[j], cA, cB);
+        const double pj = bc16(std::integral_constant<int, (j & 15)>{}, j < 16 ? cA : cB);
+        ok = ok && (pj > 0.0);
+        // symmetric (Cholesky-form) update S[l][cc] -= g_l g_cc, g = S[.][j] / sqrt(p_j): (l,cc) and (cc,l) receive
+        // bit-identical updates, so reading the column instead of the pivot row stays an exact LU of the matrix;
+        // the stored factors are unchanged (column entries S[l][j], 1/p_j)
+        const double rs = fast_rsqrt(pj);
+        if (lane == j) ipiv = rs * rs;
+        const double gA = cA * rs, gB = cB * rs;
+        const double g = (lane > j) ? Krow[j] * rs : 0.0;
+        static_for<j + 1, NV>([&](auto cc_) {
+          constexpr int cc = decltype(cc_)::value;
+          Krow[cc] = fma(-g, bc16(std::integral_constant<int, (cc & 15)>{}, cc < 16 ? gA : gB), Krow[cc]);
+        });
+      }
     });
     return ok;
   };
   auto solve = [&](double b) -> double {
-    // forward Lt w = b: w_j = b_j / p_j, b_l -= Lt[l][j] w_j (l > j); lane j's b is final after step j
-    static_for<0, NV>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      const double wj = gbcast<G, j>(b * ipiv);
-      b = fma((lane > j) ? -Krow[j] : 0.0, wj, b);
-    });
-    const double w = b * ipiv;
-    // backward Lt^T x = D w: x_j = w_j - (1/p_j) sum_{l>j} Lt[l][j] x_l, lane j holds Lt[l][j] in Krow[l];
-    // lane j's acc is final once step j+1 is done
-    double acc = 0.0;
-    static_rfor<NV, 0>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      const double xj = gbcast<G, j>(fma(-ipiv, acc, w));
-      acc = fma((lane < j) ? Krow[j] : 0.0, xj, acc);
-    });
-    return fma(-ipiv, acc, w);
+    if constexpr (G == 16) {
+      // forward Lt w = b: w_j = b_j / p_j, b_l -= Lt[l][j] w_j (l > j); lane j's b is final after step j
+      static_for<0, NV>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const double wj = gbcast<G, j>(b * ipiv);
+        b = fma((lane > j) ? -Krow[j] : 0.0, wj, b);
+      });
+      const double w = b * ipiv;
+      // backward Lt^T x = D w: x_j = w_j - (1/p_j) sum_{l>j} Lt[l][j] x_l, lane j holds Lt[l][j] in Krow[l];
+      // lane j's acc is final once step j+1 is done
+      double acc = 0.0;
+      static_rfor<NV, 0>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const double xj = gbcast<G, j>(fma(-ipiv, acc, w));
+        acc = fma((lane < j) ? Krow[j] : 0.0, xj, acc);
+      });
+      return fma(-ipiv, acc, w);
+    } else {
+      // Same recurrences, organised so that the substitution chain stays inside one DPP row at a time:
+      // columns 0..15 are eliminated among the lanes of row 0, the lanes of row 1 catch up on those 16 columns
+      // after ONE cross-row exchange of the finished w_0..w_15, then columns 16..31 run inside row 1
+      // (and the mirror image backwards).
+      const bool hi = (lane & 16) != 0;
+      static_for<0, 16>([&](auto ic) {
+        constexpr int j = decltype(ic)::value;
+        const double wj = bc16(ic, b * ipiv);
+        b = fma((!hi && lane > j) ? -Krow[j] : 0.0, wj, b);
+      });
+      {
+        double wA, wB;
+        rowpair(b * ipiv, wA, wB);                        // wA: w_0..w_15 by local lane position
+        static_for<0, 16>([&](auto ic) {
+          constexpr int j = decltype(ic)::value;
+          b = fma(hi ? -Krow[j] : 0.0, bc16(ic, wA), b);
+        });
+      }
+      static_for<0, 16>([&](auto ic) {
+        constexpr int j = 16 + decltype(ic)::value;
+        const double wj = bc16(ic, b * ipiv);
+        b = fma((hi && lane > j) ? -Krow[j] : 0.0, wj, b);
+      });
+      const double w = b * ipiv;
+      double acc = 0.0;
+      static_rfor<16, 0>([&](auto ic) {
+        constexpr int j = 16 + decltype(ic)::value;
+        const double xj = bc16(ic, fma(-ipiv, acc, w));
+        acc = fma((hi && lane < j) ? Krow[j] : 0.0, xj, acc);
+      });
+      {
+        double xA, xB;
+        rowpair(fma(-ipiv, acc, w), xA, xB);              // xB: x_16..x_31 by local lane position
+        static_for<0, 16>([&](auto ic) {
+          constexpr int j = 16 + decltype(ic)::value;
+          acc = fma(hi ? 0.0 : Krow[j], bc16(ic, xB), acc);
+        });
+      }
+      static_rfor<16, 0>([&](auto ic) {
+        constexpr int j = decltype(ic)::value;
+        const double xj = bc16(ic, fma(-ipiv, acc, w));
+        acc = fma((!hi && lane < j) ? Krow[j] : 0.0, xj, acc);
+      });
+      return fma(-ipiv, acc, w);
+    }
   };
 
   // ---- interior point ---------------------------------------------------------------------------
