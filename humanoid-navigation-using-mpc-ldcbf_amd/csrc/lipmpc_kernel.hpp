@@ -201,6 +201,14 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return fma(fma(-x, y, 1.0), y, y);
 }
 
+// x where c holds, otherwise x with its high word cleared (|value| < 2^-1042, i.e. nothing once it meets a normal
+// number in an FMA): ONE v_cndmask instead of the two a 64-bit select costs.  Use it on temporaries (broadcast
+// results, products), where the low word needs no copy.
+__device__ __forceinline__ double zero_unless(bool c, double x) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const unsigned hi = c ? (unsigned)(u >> 32) : 0u;
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned)u);
+}
 // ------------------------------------------------------------------------------------------
 // geometry: closest point on a convex ring, unit normal, inside flip (ObstaclesUtils.py:50-109)
 // contraction off so that comparisons see the same roundings as the CPU oracle
@@ -511,14 +519,15 @@ __device__ __forceinline__ StepOut step_body(
   };
   auto factor = [&]() -> bool {
     bool ok = true;
+    const int ln = lane;
     static_for<0, NV>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       if constexpr (G == 16) {
         const double pj = gbcast<G, j>(Krow[j]);
         ok = ok && (pj > 0.0);
         const double ip = fast_rcp(pj);
-        const double f = (lane > j) ? Krow[j] * ip : 0.0;
-        if (lane == j) ipiv = ip;
+        const double f = zero_unless(ln > j, Krow[j] * ip);
+        if (ln == j) ipiv = ip;
         static_for<j + 1, NV>([&](auto cc_) {
           constexpr int cc = decltype(cc_)::value;
           Krow[cc] = fma(-f, gbcast<G, j>(Krow[cc]), Krow[cc]);
@@ -535,9 +544,9 @@ __device__ __forceinline__ StepOut step_body(
         // bit-identical updates, so reading the column instead of the pivot row stays an exact LU of the matrix;
         // the stored factors are unchanged (column entries S[l][j], 1/p_j)
         const double rs = fast_rsqrt(pj);
-        if (lane == j) ipiv = rs * rs;
+        if (ln == j) ipiv = rs * rs;
         const double gA = cA * rs, gB = cB * rs;
-        const double g = (lane > j) ? Krow[j] * rs : 0.0;
+        const double g = zero_unless(ln > j, Krow[j] * rs);
         static_for<j + 1, NV>([&](auto cc_) {
           constexpr int cc = decltype(cc_)::value;
           Krow[cc] = fma(-g, bc16(std::integral_constant<int, (cc & 15)>{}, cc < 16 ? gA : gB), Krow[cc]);
@@ -547,12 +556,13 @@ __device__ __forceinline__ StepOut step_body(
     return ok;
   };
   auto solve = [&](double b) -> double {
+    const int ln = lane;
     if constexpr (G == 16) {
       // forward Lt w = b: w_j = b_j / p_j, b_l -= Lt[l][j] w_j (l > j); lane j's b is final after step j
       static_for<0, NV>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        const double wj = gbcast<G, j>(b * ipiv);
-        b = fma((lane > j) ? -Krow[j] : 0.0, wj, b);
+        const double wj = zero_unless(ln > j, gbcast<G, j>(b * ipiv));
+        b = fma(-Krow[j], wj, b);
       });
       const double w = b * ipiv;
       // backward Lt^T x = D w: x_j = w_j - (1/p_j) sum_{l>j} Lt[l][j] x_l, lane j holds Lt[l][j] in Krow[l];
@@ -560,8 +570,8 @@ __device__ __forceinline__ StepOut step_body(
       double acc = 0.0;
       static_rfor<NV, 0>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        const double xj = gbcast<G, j>(fma(-ipiv, acc, w));
-        acc = fma((lane < j) ? Krow[j] : 0.0, xj, acc);
+        const double xj = zero_unless(ln < j, gbcast<G, j>(fma(-ipiv, acc, w)));
+        acc = fma(Krow[j], xj, acc);
       });
       return fma(-ipiv, acc, w);
     } else {
@@ -569,44 +579,44 @@ __device__ __forceinline__ StepOut step_body(
       // columns 0..15 are eliminated among the lanes of row 0, the lanes of row 1 catch up on those 16 columns
       // after ONE cross-row exchange of the finished w_0..w_15, then columns 16..31 run inside row 1
       // (and the mirror image backwards).
-      const bool hi = (lane & 16) != 0;
+      const bool hi = (ln & 16) != 0;
       static_for<0, 16>([&](auto ic) {
         constexpr int j = decltype(ic)::value;
-        const double wj = bc16(ic, b * ipiv);
-        b = fma((!hi && lane > j) ? -Krow[j] : 0.0, wj, b);
+        const double wj = zero_unless(!hi && ln > j, bc16(ic, b * ipiv));
+        b = fma(-Krow[j], wj, b);
       });
       {
         double wA, wB;
         rowpair(b * ipiv, wA, wB);                        // wA: w_0..w_15 by local lane position
         static_for<0, 16>([&](auto ic) {
           constexpr int j = decltype(ic)::value;
-          b = fma(hi ? -Krow[j] : 0.0, bc16(ic, wA), b);
+          b = fma(-Krow[j], zero_unless(hi, bc16(ic, wA)), b);
         });
       }
       static_for<0, 16>([&](auto ic) {
         constexpr int j = 16 + decltype(ic)::value;
-        const double wj = bc16(ic, b * ipiv);
-        b = fma((hi && lane > j) ? -Krow[j] : 0.0, wj, b);
+        const double wj = zero_unless(hi && ln > j, bc16(ic, b * ipiv));
+        b = fma(-Krow[j], wj, b);
       });
       const double w = b * ipiv;
       double acc = 0.0;
       static_rfor<16, 0>([&](auto ic) {
         constexpr int j = 16 + decltype(ic)::value;
-        const double xj = bc16(ic, fma(-ipiv, acc, w));
-        acc = fma((hi && lane < j) ? Krow[j] : 0.0, xj, acc);
+        const double xj = zero_unless(hi && ln < j, bc16(ic, fma(-ipiv, acc, w)));
+        acc = fma(Krow[j], xj, acc);
       });
       {
         double xA, xB;
         rowpair(fma(-ipiv, acc, w), xA, xB);              // xB: x_16..x_31 by local lane position
         static_for<0, 16>([&](auto ic) {
           constexpr int j = 16 + decltype(ic)::value;
-          acc = fma(hi ? 0.0 : Krow[j], bc16(ic, xB), acc);
+          acc = fma(Krow[j], zero_unless(!hi, bc16(ic, xB)), acc);
         });
       }
       static_rfor<16, 0>([&](auto ic) {
         constexpr int j = decltype(ic)::value;
-        const double xj = bc16(ic, fma(-ipiv, acc, w));
-        acc = fma((!hi && lane < j) ? Krow[j] : 0.0, xj, acc);
+        const double xj = zero_unless(!hi && ln < j, bc16(ic, fma(-ipiv, acc, w)));
+        acc = fma(Krow[j], xj, acc);
       });
       return fma(-ipiv, acc, w);
     }
