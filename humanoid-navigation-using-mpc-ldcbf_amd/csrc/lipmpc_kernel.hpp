@@ -64,6 +64,10 @@ struct KArgs {
 //   shift by 2/4/8 stages    row_shr / row_shl with zero fill
 // G = 32 (two rows): in-row steps by DPP, cross-row steps by v_permlane16_swap_b32 (no LDS crossbar either).
 // ------------------------------------------------------------------------------------------
+// unroll factor of the loops over streamed LDCBF rows: enough independent LDS reads in flight to cover their latency
+#ifndef STREAM_UNROLL
+#define STREAM_UNROLL 5
+#endif
 template <int I, int E, class F> __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < E) {
     f(std::integral_constant<int, I>{});
@@ -665,7 +669,7 @@ __device__ __forceinline__ StepOut step_body(
     z[i] = pres[i] ? IPM_Z0 : 0.0;
   }
   if constexpr (STREAM) {
-#pragma unroll 1
+#pragma unroll STREAM_UNROLL
     for (int t = 0; t < NOBS_S; ++t) {
       double ex, ey, b;
       s_obs(t, ex, ey, b);
@@ -721,7 +725,7 @@ __device__ __forceinline__ StepOut step_body(
       if constexpr (STREAM) {
         const double qp = gxor<G, 1>(q);
         qx = c ? qp : q; qy = c ? q : qp;
-#pragma unroll 1
+#pragma unroll STREAM_UNROLL
         for (int t = 0; t < NOBS_S; ++t) {
           const SRow r = s_row(t, qx, qy);
           mu_l = fma(r.s, r.z, mu_l);
@@ -779,7 +783,7 @@ __device__ __forceinline__ StepOut step_body(
           s2_l = fma(dsa[i], dza[i], s2_l);
         }
         if constexpr (STREAM) {                            // pass B
-#pragma unroll 1
+#pragma unroll STREAM_UNROLL
           for (int t = 0; t < NOBS_S; ++t) {
             const SRow r = s_row(t, qx, qy);
             const double dsa_t = (-r.rp + (r.ex * ax_ + r.ey * ay_)) * r.pm;      // g = -eta
@@ -802,7 +806,7 @@ __device__ __forceinline__ StepOut step_body(
         }
         axs = 0.0; ays = 0.0;
         if constexpr (STREAM) {                            // pass D
-#pragma unroll 1
+#pragma unroll STREAM_UNROLL
           for (int t = 0; t < NOBS_S; ++t) {
             const SRow r = s_row(t, qx, qy);
             const double dsa_t = (-r.rp + (r.ex * ax_ + r.ey * ay_)) * r.pm;
@@ -832,7 +836,7 @@ __device__ __forceinline__ StepOut step_body(
           dz_t = -fma(r.z, ds_t, rc_t) * r.is;
         };
         if constexpr (STREAM) {                            // pass E
-#pragma unroll 1
+#pragma unroll STREAM_UNROLL
           for (int t = 0; t < NOBS_S; ++t) {
             const SRow r = s_row(t, qx, qy);
             double ds_t, dz_t;
@@ -843,7 +847,7 @@ __device__ __forceinline__ StepOut step_body(
         const double alpha = IPM_STEP_FRAC / gmax<G>(r_l);
         if (!done) {
           if constexpr (STREAM) {                          // pass F (before q moves: rows are evaluated at the old iterate)
-#pragma unroll 1
+#pragma unroll STREAM_UNROLL
             for (int t = 0; t < NOBS_S; ++t) {
               const SRow r = s_row(t, qx, qy);
               double ds_t, dz_t;
@@ -885,7 +889,7 @@ __device__ __forceinline__ StepOut step_body(
     act[i] = pres[i] && (z[i] > FIN_IDENT * s[i]);
   }
   if constexpr (STREAM) {
-#pragma unroll 1
+#pragma unroll STREAM_UNROLL
     for (int t = 0; t < NOBS_S; ++t) {
       if ((pbits >> t) & 1u) {
         const double st = lds_sz[grp][t][lane][0], zt = lds_sz[grp][t][lane][1];
@@ -910,7 +914,7 @@ __device__ __forceinline__ StepOut step_body(
 #pragma unroll
     for (int i = 0; i < NR; ++i) y[i] = act[i] ? z[i] : 0.0;
     if constexpr (STREAM) {           // the z slot of a streamed row now holds its multiplier y
-#pragma unroll 1
+#pragma unroll STREAM_UNROLL
       for (int t = 0; t < NOBS_S; ++t)
         if (!((abits >> t) & 1u)) lds_sz[grp][t][lane][1] = 0.0;
     }
@@ -921,7 +925,7 @@ __device__ __forceinline__ StepOut step_body(
       for (int i = 0; i < NR; ++i) d[i] = act[i] ? FIN_RHO : 0.0;
       double cxs = 0.0, cxys = 0.0, cys = 0.0;
       if constexpr (STREAM) {
-#pragma unroll 1
+#pragma unroll STREAM_UNROLL
         for (int t = 0; t < NOBS_S; ++t) {
           if ((abits >> t) & 1u) {
             double ex, ey, bb;
@@ -945,7 +949,7 @@ __device__ __forceinline__ StepOut step_body(
         }
         double ayx = 0.0, ayy = 0.0, awx = 0.0, awy = 0.0;
         if constexpr (STREAM) {
-#pragma unroll 1
+#pragma unroll STREAM_UNROLL
           for (int t = 0; t < NOBS_S; ++t) {
             if ((abits >> t) & 1u) {
               double ex, ey, bb;
@@ -972,7 +976,7 @@ __device__ __forceinline__ StepOut step_body(
           for (int i = 0; i < NR; ++i) if (act[i]) y[i] += FIN_RHO * (dl[i] - slk[i]);
           if constexpr (STREAM) {
             const double ddx = cx_, ddy = cy_;
-#pragma unroll 1
+#pragma unroll STREAM_UNROLL
             for (int t = 0; t < NOBS_S; ++t) {
               if ((abits >> t) & 1u) {
                 double ex, ey, bb;
@@ -996,7 +1000,7 @@ __device__ __forceinline__ StepOut step_body(
       }
       if constexpr (STREAM) {
         const double fx = cx_, fy = cy_;
-#pragma unroll 1
+#pragma unroll STREAM_UNROLL
         for (int t = 0; t < NOBS_S; ++t) {
           if ((pbits >> t) & 1u) {
             const int ci = ci_s(t);
@@ -1020,7 +1024,7 @@ __device__ __forceinline__ StepOut step_body(
 #pragma unroll
           for (int i = 0; i < NR; ++i) if (act[i] && ci_of(i) == yi) { act[i] = false; y[i] = 0.0; }
           if constexpr (STREAM) {
-#pragma unroll 1
+#pragma unroll STREAM_UNROLL
             for (int t = 0; t < NOBS_S; ++t)
               if (((abits >> t) & 1u) && ci_s(t) == yi) { abits &= ~(1u << t); lds_sz[grp][t][lane][1] = 0.0; }
           }
@@ -1028,7 +1032,7 @@ __device__ __forceinline__ StepOut step_body(
 #pragma unroll
           for (int i = 0; i < NR; ++i) if (pres[i] && !act[i] && ci_of(i) == si) act[i] = true;
           if constexpr (STREAM) {
-#pragma unroll 1
+#pragma unroll STREAM_UNROLL
             for (int t = 0; t < NOBS_S; ++t)
               if (((pbits >> t) & 1u) && !((abits >> t) & 1u) && ci_s(t) == si) abits |= 1u << t;
           }
@@ -1072,7 +1076,7 @@ __device__ __forceinline__ StepOut step_body(
       if (act[i]) atomicOr(&lds_act[grp][ci >> 6], 1ull << (ci & 63));
     }
     if constexpr (STREAM) {
-#pragma unroll 1
+#pragma unroll STREAM_UNROLL
       for (int t = 0; t < NOBS_S; ++t) {
         const int ci = ci_s(t);
         if ((abits >> t) & 1u) atomicOr(&lds_act[grp][ci >> 6], 1ull << (ci & 63));
