@@ -67,7 +67,7 @@ int lipmpc_create(const lipmpc_params* p, int device, lipmpc_handle** out) {
   h->device = device;
   h->G = (p->N <= 8) ? 16 : 32;
   const int need = (p->n_obs_max + 1) / 2;
-  h->nobs_l = need == 0 ? 0 : need <= 2 ? 2 : need <= 5 ? 5 : need <= 13 ? 13 : 25;
+  h->nobs_l = need == 0 ? 0 : need <= 2 ? 2 : need <= 5 ? 5 : need <= 7 ? 7 : need <= 13 ? 13 : 25;
   KArgs& k = h->k;
   k.N = p->N; k.n_obs = p->n_obs_max; k.nvert_max = p->v_max; k.max_iter = p->max_iter; k.flags = p->flags;
   k.m_tot = (int)lipmpc_num_rows(p); k.words = (int)lipmpc_active_words(p);
@@ -104,6 +104,7 @@ int lipmpc_plan_step_batch(lipmpc_handle* h, int64_t B, const double* state, con
       case 0: LAUNCH(16, 0); break;
       case 2: LAUNCH(16, 2); break;
       case 5: LAUNCH(16, 5); break;
+      case 7: LAUNCH(16, 7); break;
       case 13: LAUNCH(16, 13); break;
       default: LAUNCH(16, 25); break;
     }
@@ -112,6 +113,7 @@ int lipmpc_plan_step_batch(lipmpc_handle* h, int64_t B, const double* state, con
       case 0: LAUNCH(32, 0); break;
       case 2: LAUNCH(32, 2); break;
       case 5: LAUNCH(32, 5); break;
+      case 7: LAUNCH(32, 7); break;
       case 13: LAUNCH(32, 13); break;
       default: LAUNCH(32, 25); break;
     }
@@ -139,6 +141,7 @@ int lipmpc_rollout_batch(lipmpc_handle* h, int64_t B, int32_t k_max, int32_t mpc
       case 0: LAUNCH_RO(16, 0); break;
       case 2: LAUNCH_RO(16, 2); break;
       case 5: LAUNCH_RO(16, 5); break;
+      case 7: LAUNCH_RO(16, 7); break;
       case 13: LAUNCH_RO(16, 13); break;
       default: LAUNCH_RO(16, 25); break;
     }
@@ -147,6 +150,7 @@ int lipmpc_rollout_batch(lipmpc_handle* h, int64_t B, int32_t k_max, int32_t mpc
       case 0: LAUNCH_RO(32, 0); break;
       case 2: LAUNCH_RO(32, 2); break;
       case 5: LAUNCH_RO(32, 5); break;
+      case 7: LAUNCH_RO(32, 7); break;
       case 13: LAUNCH_RO(32, 13); break;
       default: LAUNCH_RO(32, 25); break;
     }

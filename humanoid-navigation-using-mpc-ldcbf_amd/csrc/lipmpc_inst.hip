@@ -1,5 +1,5 @@
 // lipmpc_inst.hip — one explicit instantiation of the step kernel per object file:
-// compiled with -DINST_G=<16|32> -DINST_NL=<0|2|5|13|25> (see Makefile).
+// compiled with -DINST_G=<16|32> -DINST_NL=<0|2|5|7|13|25> (see Makefile).
 #include "lipmpc_kernel.hpp"
 
 namespace lipmpc_dev {

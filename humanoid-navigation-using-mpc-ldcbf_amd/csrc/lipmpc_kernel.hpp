@@ -300,7 +300,7 @@ __device__ __forceinline__ StepOut step_body(
   // LDCBF rows of a lane live in registers for small obstacle sets (NOBS_R of them) and are STREAMED for
   // large ones: only (s, z) per row is kept, in LDS, and every pass over the rows recomputes the rest from
   // the obstacle's (eta, b) in LDS and the stage's position — no per-row register state, no spills.
-  constexpr bool STREAM = NOBS_L > 5;
+  constexpr bool STREAM = NOBS_L > 7;
   constexpr int NOBS_R = STREAM ? 0 : NOBS_L;
   constexpr int NOBS_S = STREAM ? NOBS_L : 0;
   constexpr int NR = R_CBF + NOBS_R;   // local row slots held in registers

@@ -8,26 +8,30 @@
 // One wavefront (64 lanes) per robot; everything between the ray casting and the rings stays in LDS:
 //   1. rays: lane l owns rays l, l+64, ...; every ray walks obstacles in list order and edges in ring order and keeps
 //      the nearest hit strictly inside the range (contraction off: the hit points are bit-identical to the reference's)
-//   2. DBSCAN(eps, min_samples) by its order-free characterisation (oracle/lidar_oracle.py): neighbour bit rows,
-//      core flags, connected components of core points by min-label propagation + pointer jumping, clusters numbered
-//      by their smallest core index, border points to the smallest neighbouring cluster
+//   2. DBSCAN(eps, min_samples) by its order-free characterisation (oracle/lidar_oracle.py), on the readings
+//      compacted in ray order: neighbour bit rows, core flags, connected components of the core points (forest of
+//      "smallest core neighbour" pointers + pointer jumping, then merging trees through ballot masks of tree
+//      membership — bit operations, no sweeps over neighbours' labels), clusters numbered by their smallest core
+//      index, border points to the smallest neighbouring cluster
 //   3. hull per cluster: Jarvis march from the lexicographically smallest point, farthest point on collinear ties
-//      (= the CCW ring of extreme points Qhull / monotone chain return, same rotation as np.unique + monotone chain)
+//      (= the CCW ring of extreme points Qhull / monotone chain return, same rotation as np.unique + monotone chain);
+//      four clusters march at once, one per 16-lane DPP row, over compacted member lists
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
-#include "../../include/lipmpc.h"
+#include "lipmpc_kernel.hpp"      // DPP row exchanges (lipmpc_dev::row_xor)
 
 namespace {
 
 constexpr int RMAX = 384;            // rays per scan (reference: 360)
 constexpr int WORDS = RMAX / 64;     // neighbour bit row
 constexpr int NO_ROOT = 0x7fffffff;
+constexpr int VSTAGE = 64;          // hull vertices staged per cluster (v_max <= VSTAGE)
 
 struct Cand { double x, y; int idx; };
 
-__device__ __forceinline__ double shfl_d(double v, int m) { return __shfl_xor(v, m, 64); }
 
 // is candidate b a better "next hull vertex" than a when standing on p?  (b strictly to the right of p->a, or
 // collinear and farther; a.idx < 0 = no candidate yet; points equal to p are never candidates)
@@ -48,7 +52,7 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
     int n_obs_max, int v_max, const double* __restrict__ state, const double* __restrict__ env_xy,
     const int32_t* __restrict__ env_nv, const double* __restrict__ ray_table, const double* __restrict__ noise,
     double* __restrict__ obs_xy, int32_t* __restrict__ obs_nv, int32_t* __restrict__ n_inferred,
-    int32_t* __restrict__ overflow, double* __restrict__ hits_out, int32_t* __restrict__ labels_out) {
+    int32_t* __restrict__ overflow, double* __restrict__ hits_out, int32_t* __restrict__ labels_out, int dbg_stop) {
   __shared__ double px_[RMAX], py_[RMAX];
   __shared__ __attribute__((aligned(16))) int comp_[RMAX];                    // -1 = no reading; core: component root; else NO_ROOT
   __shared__ int root_[RMAX];                    // cluster root of every reading (NO_ROOT = noise)
@@ -132,18 +136,46 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
   }
   __syncthreads();
 
+  if (dbg_stop == 1) return;
   // ---- 2. DBSCAN ------------------------------------------------------------------------------------
+  // Readings are first compacted in ray order (typically 110-200 of 360 rays return one): clustering and hulls then
+  // sweep n points instead of RMAX slots.  Order is preserved, so "smallest core index" numbering, border-point
+  // assignment and every index tie-break are those of the uncompacted scan.  In place: slot k <= i always, one
+  // word of 64 rays is read by the whole wave before its survivors are written back.
+  int n_pts = 0;
+  for (int w = 0; w < WORDS; ++w) {
+    const int i = w * 64 + lane;
+    const bool have = comp_[i] >= 0;
+    const double hx = px_[i], hy = py_[i];
+    const unsigned long long ball = __ballot(have);
+    __syncthreads();
+    if (have) {
+      const int k = n_pts + __popcll(ball & ((1ull << lane) - 1ull));
+      px_[k] = hx; py_[k] = hy; cand_[k] = i;               // cand_ is free after the ray casting: ray of point k
+    }
+    n_pts += __popcll(ball);
+    __syncthreads();
+  }
+  const int NW = (n_pts + 63) >> 6;                      // words / passes actually in use (wave-uniform)
+  const int npad = NW << 6;
+  for (int i = lane; i < RMAX; i += 64) comp_[i] = (i < n_pts) ? NO_ROOT : -1;
+  if (labels_out) for (int i = lane; i < R; i += 64) labels_out[b * R + i] = -2;      // -2 = no reading
+  __syncthreads();
   const double eps2 = eps * eps;
-  unsigned long long vmask[WORDS];                  // which readings exist, one ballot per 64 rays
+  unsigned long long vmask[WORDS];                  // which points exist
 #pragma unroll
-  for (int w = 0; w < WORDS; ++w) vmask[w] = __ballot(comp_[w * 64 + lane] >= 0);
-  for (int i = lane; i < RMAX; i += 64) {
+  for (int w = 0; w < WORDS; ++w) {
+    const int left = n_pts - w * 64;
+    vmask[w] = left >= 64 ? ~0ull : (left <= 0 ? 0ull : ((1ull << left) - 1ull));
+  }
+  for (int i = lane; i < npad; i += 64) {
     int cnt = 0;
     const bool vi = comp_[i] >= 0;
     const double xi = px_[i], yi = py_[i];
 #pragma unroll
     for (int w = 0; w < WORDS; ++w) {
-      // counted, unrolled sweep over all 64 slots of the word (loads pipeline; absent readings are masked after)
+      if (w >= NW) { nb_[i][w] = 0ull; continue; }
+      // counted, unrolled sweep over all 64 slots of the word (loads pipeline; absent points are masked after)
       unsigned long long bits = 0ull;
 #pragma unroll 16
       for (int k = 0; k < 64; ++k) {
@@ -158,75 +190,110 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
     root_[i] = (vi && cnt >= min_samples) ? i : NO_ROOT;      // core points start as their own root
   }
   __syncthreads();
-  for (int i = lane; i < RMAX; i += 64) if (comp_[i] >= 0) comp_[i] = root_[i];
+  for (int i = lane; i < npad; i += 64) if (comp_[i] >= 0) comp_[i] = root_[i];
   __syncthreads();
-  // connected components of the core points (hook: min over core neighbours; then pointer jumping to the root;
-  // repeat until a hook round changes nothing — a handful of rounds instead of one per hop of the longest chain)
+  if (dbg_stop == 2) return;
+  // Connected components of the core points, label = smallest core index of the component.
+  //  (1) forest: every core point points at its smallest core neighbour (lowest set bit of its neighbour row — no
+  //      label reads), pointer jumping flattens the trees;
+  //  (2) merge: per tree root r (ascending, a scalar loop) the membership mask M_r of its tree is one ballot per
+  //      word, and "point i touches tree r" is (row_i & M_r) != 0 — register bit operations against wave-uniform
+  //      masks instead of a sweep over the neighbours' labels.  The first tree a point touches is the smallest;
+  //      a point whose tree root is larger hooks its root under it (atomicMin), pointer jumping, repeat until no
+  //      hook happens (typically one or two rounds).
+  // The last round also yields, for the non-core points, the smallest neighbouring cluster (border points).
   unsigned long long cmask[WORDS];
 #pragma unroll
   for (int w = 0; w < WORDS; ++w) { const int cj = comp_[w * 64 + lane]; cmask[w] = __ballot(cj >= 0 && cj != NO_ROOT); }
-  for (int round = 0; round < RMAX; ++round) {
-    bool changed = false;
-    for (int i = lane; i < RMAX; i += 64) {
-      const int ci = comp_[i];
-      bool mine = false;
-      if (ci >= 0 && ci != NO_ROOT) {
-        mine = true;
-      }
-      // lanes of one pass own rays i = lane + 64 k: their neighbours sit in the same few words, so a word is
-      // swept by the whole wave with independent (pipelined, broadcast) LDS reads or skipped by the whole wave
-      int m = mine ? ci : NO_ROOT;
+  unsigned long long row[WORDS][WORDS];             // row[k][w]: neighbour bits of point lane + 64 k, word w
+#pragma unroll
+  for (int k = 0; k < WORDS; ++k) {
+#pragma unroll
+    for (int w = 0; w < WORDS; ++w) row[k][w] = (k < NW && w < NW) ? nb_[k * 64 + lane][w] : 0ull;
+  }
+#pragma unroll
+  for (int k = 0; k < WORDS; ++k) {
+    if (k >= NW) continue;
+    const int i = k * 64 + lane;
+    const int ci = comp_[i];
+    if (ci >= 0 && ci != NO_ROOT) {
+      int p = i;
+      bool found = false;
 #pragma unroll
       for (int w = 0; w < WORDS; ++w) {
-        const unsigned long long bits = mine ? (nb_[i][w] & cmask[w]) : 0ull;
-        if (__any(bits != 0ull)) {
-#pragma unroll 4
-          for (int k4 = 0; k4 < 16; ++k4) {
-            const int4 c4 = *reinterpret_cast<const int4*>(&comp_[w * 64 + k4 * 4]);
-            const unsigned nib = (unsigned)(bits >> (k4 * 4)) & 0xfu;
-            m = (nib & 1u) ? min(m, c4.x) : m;
-            m = (nib & 2u) ? min(m, c4.y) : m;
-            m = (nib & 4u) ? min(m, c4.z) : m;
-            m = (nib & 8u) ? min(m, c4.w) : m;
-          }
-        }
+        const unsigned long long bits = row[k][w] & cmask[w];
+        if (!found && bits != 0ull) { p = w * 64 + __ffsll((long long)bits) - 1; found = true; }
       }
-      if (mine && m < ci) { comp_[i] = m; changed = true; }
+      comp_[i] = p;                                   // p <= i: a core point is its own neighbour
     }
-    __syncthreads();
-    for (int jump = 0; jump < 4; ++jump) {
-      for (int i = lane; i < RMAX; i += 64) {
-        const int ci = comp_[i];
-        if (ci >= 0 && ci != NO_ROOT) { const int cc = comp_[ci]; if (cc < ci) comp_[i] = cc; }
-      }
-      __syncthreads();
-    }
-    if (!__any(changed)) break;
-  }
-  // cluster root of every reading: own component for cores, smallest neighbouring core component for the rest
-  for (int i = lane; i < RMAX; i += 64) {
-    const int ci = comp_[i];
-    int r = NO_ROOT;
-    if (ci >= 0) {
-      if (ci != NO_ROOT) r = ci;
-      else {
-        for (int w = 0; w < WORDS; ++w) {
-          unsigned long long bits = nb_[i][w];
-          while (bits) {
-            const int k = __ffsll((long long)bits) - 1;
-            bits &= bits - 1;
-            const int cj = comp_[w * 64 + k];
-            if (cj != NO_ROOT && cj < r) r = cj;
-          }
-        }
-      }
-    }
-    root_[i] = r;
   }
   __syncthreads();
+  auto flatten = [&]() {
+    for (int jump = 0; jump < 16; ++jump) {
+      bool moved = false;
+      for (int i = lane; i < npad; i += 64) {
+        const int ci = comp_[i];
+        if (ci >= 0 && ci != NO_ROOT) { const int cc = comp_[ci]; if (cc < ci) { comp_[i] = cc; moved = true; } }
+      }
+      __syncthreads();
+      if (!__any(moved)) break;
+    }
+  };
+  flatten();
+  int touch[WORDS];                                  // smallest tree root point lane + 64 k touches (NO_ROOT: none)
+  for (int round = 0; round < RMAX; ++round) {
+    int cw[WORDS];
+    unsigned long long rootmask[WORDS];
+#pragma unroll
+    for (int w = 0; w < WORDS; ++w) {
+      cw[w] = comp_[w * 64 + lane];
+      rootmask[w] = __ballot(cw[w] == w * 64 + lane);
+      touch[w] = NO_ROOT;
+    }
+#pragma unroll
+    for (int wr = 0; wr < WORDS; ++wr) {
+      if (wr >= NW) continue;
+      unsigned long long rm = rootmask[wr];            // wave-uniform
+      while (rm) {
+        const int r = wr * 64 + __ffsll((long long)rm) - 1;
+        rm &= rm - 1;
+        unsigned long long M[WORDS];
+#pragma unroll
+        for (int w = 0; w < WORDS; ++w) M[w] = __ballot(cw[w] == r);
+#pragma unroll
+        for (int k = 0; k < WORDS; ++k) {
+          unsigned long long hit = 0ull;
+#pragma unroll
+          for (int w = 0; w < WORDS; ++w) hit |= row[k][w] & M[w];
+          if (hit != 0ull && touch[k] == NO_ROOT) touch[k] = r;
+        }
+      }
+    }
+    bool changed = false;
+#pragma unroll
+    for (int k = 0; k < WORDS; ++k) {
+      if (k >= NW) continue;
+      const int own = cw[k];
+      if (own >= 0 && own != NO_ROOT && touch[k] < own) { atomicMin(&comp_[own], touch[k]); changed = true; }
+    }
+    __syncthreads();
+    if (!__any(changed)) break;
+    flatten();
+  }
+  if (dbg_stop == 4) return;
+  // cluster root of every reading: own component for cores, smallest neighbouring core component for the rest
+#pragma unroll
+  for (int k = 0; k < WORDS; ++k) {
+    if (k >= NW) continue;
+    const int i = k * 64 + lane;
+    const int ci = comp_[i];
+    root_[i] = (ci < 0) ? NO_ROOT : ((ci != NO_ROOT) ? ci : touch[k]);
+  }
+  __syncthreads();
+  if (dbg_stop == 5) return;
   // roots in ascending order = cluster labels 0, 1, ...
   int n_clusters = 0;
-  for (int w = 0; w < WORDS; ++w) {
+  for (int w = 0; w < NW; ++w) {
     const int i = w * 64 + lane;
     const bool is_root = comp_[i] == i;
     const unsigned long long ball = __ballot(is_root);
@@ -238,64 +305,109 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
   }
   __syncthreads();
   if (labels_out) {
-    for (int i = lane; i < R; i += 64) {
-      int lab = -2;                                           // -2 no reading, -1 noise
-      if (comp_[i] >= 0) {
-        lab = -1;
-        const int r = root_[i];
-        if (r != NO_ROOT) for (int k = 0; k < n_clusters && k < 64; ++k) if (roots_[k] == r) lab = k;
-      }
-      labels_out[b * R + i] = lab;
+    for (int i = lane; i < n_pts; i += 64) {
+      int lab = -1;                                           // -1 noise
+      const int r = root_[i];
+      if (r != NO_ROOT) for (int k = 0; k < n_clusters && k < 64; ++k) if (roots_[k] == r) lab = k;
+      labels_out[b * R + cand_[i]] = lab;
     }
   }
 
+  if (dbg_stop == 3) return;
   // ---- 3. convex hull per cluster (create_convex_hull) ------------------------------------------------
+  // Four clusters at a time, one per 16-lane DPP row: a row walks its own cluster's member list (compacted below) and
+  // every "best next vertex" reduction is four in-row DPP steps — no LDS crossbar, no cross-row traffic.  Vertices
+  // are staged in LDS (the neighbour rows are dead by now) and committed in cluster order for proper polygons only.
   int n_out = 0, ovf = (n_clusters > 64) ? 1 : 0;
   double* oxy = obs_xy + b * (long)n_obs_max * v_max * 2;
   int32_t* onv = obs_nv + b * (long)n_obs_max;
   for (int k = lane; k < n_obs_max; k += 64) onv[k] = 0;
-  for (int k = 0; k < n_clusters && k < 64; ++k) {
-    const int r = roots_[k];
+  const int nc = n_clusters < 64 ? n_clusters : 64;
+  int* list_ = cand_;                                   // member lists, cluster after cluster (labels are written)
+  int* coff_ = comp_;                                   // coff_[k] .. coff_[k+1]: members of cluster k
+  double* stage_ = reinterpret_cast<double*>(&nb_[0][0]);   // [4][VSTAGE][2]
+  double* cx_ = stage_ + 4 * VSTAGE * 2;                  // points in member-list order (direct, pipelined reads)
+  double* cy_ = cx_ + RMAX;
+  __syncthreads();
+  {
+    int off = 0;
+    for (int k = 0; k < nc; ++k) {
+      const int r = roots_[k];
+      if (lane == 0) coff_[k] = off;
+      for (int w = 0; w < NW; ++w) {
+        const int i = w * 64 + lane;
+        const bool m = root_[i] == r;
+        const unsigned long long ball = __ballot(m);
+        if (m) {
+          const int pos = off + __popcll(ball & ((1ull << lane) - 1ull));
+          list_[pos] = i; cx_[pos] = px_[i]; cy_[pos] = py_[i];
+        }
+        off += __popcll(ball);
+      }
+    }
+    if (lane == 0) coff_[nc] = off;
+  }
+  __syncthreads();
+  const int q = lane >> 4, l16 = lane & 15;
+  auto row_best = [&](Cand& c, auto&& take_other) {     // butterfly over the 16 lanes of the row
+    { Cand o; o.x = lipmpc_dev::row_xor<1>(c.x); o.y = lipmpc_dev::row_xor<1>(c.y); o.idx = lipmpc_dev::row_xor<1>(c.idx); if (take_other(c, o)) c = o; }
+    { Cand o; o.x = lipmpc_dev::row_xor<2>(c.x); o.y = lipmpc_dev::row_xor<2>(c.y); o.idx = lipmpc_dev::row_xor<2>(c.idx); if (take_other(c, o)) c = o; }
+    { Cand o; o.x = lipmpc_dev::row_xor<4>(c.x); o.y = lipmpc_dev::row_xor<4>(c.y); o.idx = lipmpc_dev::row_xor<4>(c.idx); if (take_other(c, o)) c = o; }
+    { Cand o; o.x = lipmpc_dev::row_xor<8>(c.x); o.y = lipmpc_dev::row_xor<8>(c.y); o.idx = lipmpc_dev::row_xor<8>(c.idx); if (take_other(c, o)) c = o; }
+  };
+  for (int g = 0; g < nc; g += 4) {
+    const int k = g + q;
+    const bool on = k < nc;
+    const int beg = on ? coff_[k] : 0, end = on ? coff_[k + 1] : 0;
     // lexicographically smallest point of the cluster
     Cand st; st.idx = -1; st.x = 0.0; st.y = 0.0;
-    for (int i = lane; i < RMAX; i += 64) {
-      if (root_[i] == r) {
-        const double x = px_[i], y = py_[i];
-        if (st.idx < 0 || x < st.x || (x == st.x && (y < st.y || (y == st.y && i < st.idx)))) { st.x = x; st.y = y; st.idx = i; }
-      }
+    for (int t = beg + l16; t < end; t += 16) {
+      const int i = list_[t];
+      const double x = cx_[t], y = cy_[t];
+      if (st.idx < 0 || x < st.x || (x == st.x && (y < st.y || (y == st.y && i < st.idx)))) { st.x = x; st.y = y; st.idx = i; }
     }
-    for (int m = 1; m < 64; m <<= 1) {
-      Cand o; o.x = shfl_d(st.x, m); o.y = shfl_d(st.y, m); o.idx = __shfl_xor(st.idx, m, 64);
-      const bool take = o.idx >= 0 && (st.idx < 0 || o.x < st.x || (o.x == st.x && (o.y < st.y || (o.y == st.y && o.idx < st.idx))));
-      if (take) st = o;
-    }
-    // Jarvis march; vertices are buffered in the output slot n_out and committed only for a proper polygon
+    row_best(st, [](const Cand& a, const Cand& o) {
+      return o.idx >= 0 && (a.idx < 0 || o.x < a.x || (o.x == a.x && (o.y < a.y || (o.y == a.y && o.idx < a.idx))));
+    });
+    // Jarvis march of the four rows in lock step
     double cxp = st.x, cyp = st.y;
     int nvert = 0;
-    const bool room = n_out < n_obs_max;
+    bool done = !on;
     for (int step = 0; step <= v_max; ++step) {
-      if (room && nvert < v_max && lane == 0) { oxy[((long)n_out * v_max + nvert) * 2] = cxp; oxy[((long)n_out * v_max + nvert) * 2 + 1] = cyp; }
-      ++nvert;
+      if (__all(done)) break;
+      if (!done && nvert < VSTAGE && l16 == 0) { stage_[(q * VSTAGE + nvert) * 2] = cxp; stage_[(q * VSTAGE + nvert) * 2 + 1] = cyp; }
+      if (!done) ++nvert;
       Cand best; best.idx = -1; best.x = 0.0; best.y = 0.0;
-      for (int i = lane; i < RMAX; i += 64) {
-        if (root_[i] == r) {
-          Cand cnd; cnd.x = px_[i]; cnd.y = py_[i]; cnd.idx = i;
-          if (!(cnd.x == cxp && cnd.y == cyp) && better(cxp, cyp, best, cnd)) best = cnd;
+      for (int t = beg + l16; t < end; t += 32) {               // two independent candidates per trip
+        const int t2 = t + 16;
+        const bool two = t2 < end;
+        Cand c1, c2;
+        c1.x = cx_[t]; c1.y = cy_[t]; c1.idx = list_[t];
+        c2.x = cx_[two ? t2 : t]; c2.y = cy_[two ? t2 : t]; c2.idx = two ? list_[t2] : -1;
+        if (!(c1.x == cxp && c1.y == cyp) && better(cxp, cyp, best, c1)) best = c1;
+        if (two && !(c2.x == cxp && c2.y == cyp) && better(cxp, cyp, best, c2)) best = c2;
+      }
+      row_best(best, [&](const Cand& a, const Cand& o) { return better(cxp, cyp, a, o); });
+      if (!done) {
+        if (best.idx < 0) done = true;                                   // single (repeated) point
+        else if (best.x == st.x && best.y == st.y) done = true;          // ring closed
+        else { cxp = best.x; cyp = best.y; }
+      }
+    }
+    __syncthreads();
+    // < 3 extreme points = fewer than 3 unique points or a collinear cluster: the reference drops it (:70-76)
+    for (int qq = 0; qq < 4 && g + qq < nc; ++qq) {
+      const int nv = __shfl(nvert, qq * 16, 64);
+      if (nv >= 3) {
+        if (n_out >= n_obs_max || nv > v_max) ovf = 1;
+        else {
+          for (int v = lane; v < nv * 2; v += 64) oxy[(long)n_out * v_max * 2 + v] = stage_[qq * VSTAGE * 2 + v];
+          if (lane == 0) onv[n_out] = nv;
+          ++n_out;
         }
       }
-      for (int m = 1; m < 64; m <<= 1) {
-        Cand o; o.x = shfl_d(best.x, m); o.y = shfl_d(best.y, m); o.idx = __shfl_xor(best.idx, m, 64);
-        if (better(cxp, cyp, best, o)) best = o;
-      }
-      if (best.idx < 0) break;                                   // single (repeated) point
-      if (best.x == st.x && best.y == st.y) break;               // ring closed
-      cxp = best.x; cyp = best.y;
     }
-    // < 3 extreme points = fewer than 3 unique points or a collinear cluster: the reference drops it (:70-76)
-    if (nvert >= 3) {
-      if (!room || nvert > v_max) ovf = 1;
-      else { if (lane == 0) onv[n_out] = nvert; ++n_out; }
-    }
+    __syncthreads();
   }
   if (lane == 0) { n_inferred[b] = n_out; overflow[b] = ovf; }
 }
@@ -308,13 +420,15 @@ extern "C" int lipmpc_lidar_sense_batch(int device, int64_t B, int32_t resolutio
                                         const int32_t* env_nv, const double* ray_table, const double* noise,
                                         double* obs_xy, int32_t* obs_nv, int32_t* n_inferred, int32_t* overflow,
                                         double* hits, int32_t* labels, void* hip_stream) {
-  if (B < 0 || resolution < 1 || resolution > RMAX || n_env < 0 || v_env < 1 || n_obs_max < 1 || v_max < 3) return LIPMPC_E_ARG;
+  if (B < 0 || resolution < 1 || resolution > RMAX || n_env < 0 || v_env < 1 || n_obs_max < 1 || v_max < 3 || v_max > VSTAGE) return LIPMPC_E_ARG;
   if (B == 0) return LIPMPC_OK;
   if (!state || !ray_table || !obs_xy || !obs_nv || !n_inferred || !overflow || (n_env > 0 && (!env_xy || !env_nv)))
     return LIPMPC_E_ARG;
   if (hipSetDevice(device) != hipSuccess) return LIPMPC_E_HIP;
+  // profiling aid (tools/lidar_phases.py): LIPMPC_LIDAR_STOP=1..5 ends the kernel after that phase; outputs are then undefined
+  static const int dbg_stop = getenv("LIPMPC_LIDAR_STOP") ? atoi(getenv("LIPMPC_LIDAR_STOP")) : 0;
   hipLaunchKernelGGL(lidar_sense_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)hip_stream, (long)B, resolution, n_env,
                      v_env, (long)(env_shared ? 0 : 1), lidar_range, eps, min_samples, n_obs_max, v_max, state, env_xy, env_nv,
-                     ray_table, noise, obs_xy, obs_nv, n_inferred, overflow, hits, labels);
+                     ray_table, noise, obs_xy, obs_nv, n_inferred, overflow, hits, labels, dbg_stop);
   return hipGetLastError() == hipSuccess ? LIPMPC_OK : LIPMPC_E_HIP;
 }

@@ -75,7 +75,7 @@ def test_smoke_single_problem_no_obstacles():
     assert s["worst_u"] < 1e-8
 
 
-@pytest.mark.parametrize("N,n_obs,ntraj,steps", [(3, 3, 6, 25), (5, 3, 4, 20), (8, 10, 6, 25)])
+@pytest.mark.parametrize("N,n_obs,ntraj,steps", [(3, 3, 6, 25), (5, 3, 4, 20), (8, 10, 6, 25), (8, 13, 4, 20)])
 def test_closed_loop_states_match_oracle(N, n_obs, ntraj, steps):
     probs = list(closed_loop_problems(N, n_obs, ntraj, steps, seed=100 + N))
     assert len(probs) > 50

@@ -22,4 +22,4 @@ def run(N,n_obs):
         e1.record(); torch.cuda.synchronize(); ts[mi]=e0.elapsed_time(e1)/30*1e3
         assert int(out['iters'][0])==mi, int(out['iters'][0])
     print(f"N={N} n_obs={n_obs}: per-iteration {(ts[8]-ts[3])/5:.3f} us, fixed {ts[3]-3*(ts[8]-ts[3])/5:.1f} us")
-for N,n_obs in ((8,0),(8,4),(8,10),(8,26),(16,0),(16,4),(16,10),(16,50)): run(N,n_obs)
+for N,n_obs in ((8,0),(8,4),(8,10),(8,12),(8,14),(8,16),(8,26),(16,0),(16,10),(16,14),(16,50)): run(N,n_obs)
