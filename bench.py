@@ -232,6 +232,22 @@ def other_configs(lipmpc, synth, dev):
                             "robot_steps_per_s": B / (ms_scan + ms_step) * 1e3,
                             "mean_inferred_obstacles": float(sen["n_inferred"].double().mean()),
                             "overflow": int(sen["overflow"].sum())}
+    # config 5 in closed loop: the same fleet walking 30 samples through the map, one captured HIP graph per sample
+    fleet = lipmpc.UnknownEnvFleet(rings, N_horizon=N, lidar_range=1.5, resolution=360, n_obs_max=12, v_max=32, device=dev.index)
+    st0 = torch.zeros((B, 5), dtype=torch.float64, device=dev)
+    st0[:, 0] = -1.8 + 0.5 * torch.rand((B,), dtype=torch.float64, device=dev, generator=gen)
+    st0[:, 2] = -1.5 + 7.5 * torch.rand((B,), dtype=torch.float64, device=dev, generator=gen)
+    K = 30
+    fleet.run(st0, goal, foot, 3)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    r = fleet.run(st0, goal, foot, K, noise_seed=5)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    solved = int(r["n_steps"].sum())
+    out["config5_closed_loop"] = {"robots": B, "samples": K, "ms": dt * 1e3, "robot_steps_solved": solved,
+                                  "robot_steps_per_s": solved / dt, "robots_walking_at_end": int((r["n_steps"] == K).sum()),
+                                  "overflow_samples": int(r["overflow"].sum())}
     return out
 
 

@@ -3,4 +3,4 @@ solve of salvatore373/Humanoid-Navigation-using-MPC-LDCBF, HumanoidNavigation/MP
 from .solver import (BatchedLipMpc, LipMpcParams, pack_rings, unpack_active, FLAG_INTERIOR,  # noqa: F401
                      STATUS_SOLVED, STATUS_MAX_ITER, STATUS_INFEASIBLE, STATUS_DEGENERATE, STATUS_UNCERTIFIED)
 from .compat import HumanoidMPC, HumanoidMPCCustomLCBF, HumanoidMPCWithRRT  # noqa: F401
-from .lidar import LidarSensor, HumanoidMPCUnknownEnvironment, ray_table  # noqa: F401
+from .lidar import LidarSensor, HumanoidMPCUnknownEnvironment, UnknownEnvFleet, ray_table  # noqa: F401

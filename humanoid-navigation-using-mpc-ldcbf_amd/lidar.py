@@ -45,9 +45,8 @@ class LidarSensor:
         self.env_nv = torch.as_tensor(nv, device=self.device)
         self.table = torch.as_tensor(ray_table(self.resolution), device=self.device)
 
-    def sense(self, state, noise=None, with_debug=False):
-        """state [B,5] device tensor; noise [B,resolution,2] or None -> dict(obs_xy, obs_nv, n_inferred, overflow[, hits, labels])."""
-        B, dev = state.shape[0], self.device
+    def alloc_outputs(self, B, with_debug=False):
+        dev = self.device
         out = dict(obs_xy=torch.zeros((B, self.n_obs_max, self.v_max, 2), dtype=torch.float64, device=dev),
                    obs_nv=torch.zeros((B, self.n_obs_max), dtype=torch.int32, device=dev),
                    n_inferred=torch.zeros((B,), dtype=torch.int32, device=dev),
@@ -55,6 +54,14 @@ class LidarSensor:
         if with_debug:
             out["hits"] = torch.empty((B, self.resolution, 2), dtype=torch.float64, device=dev)
             out["labels"] = torch.empty((B, self.resolution), dtype=torch.int32, device=dev)
+        return out
+
+    def sense(self, state, noise=None, with_debug=False, out=None):
+        """state [B,5] device tensor; noise [B,resolution,2] or None -> dict(obs_xy, obs_nv, n_inferred, overflow[, hits, labels]).
+        Vertex slots beyond obs_nv keep whatever an earlier call left there when ``out`` is reused."""
+        B, dev = state.shape[0], self.device
+        if out is None:
+            out = self.alloc_outputs(B, with_debug)
         stream = torch.cuda.current_stream(dev).cuda_stream
         rc = self.lib.lipmpc_lidar_sense_batch(
             self.device_index, B, self.resolution, self.n_env, self.v_env, 1, self.lidar_range, DBSCAN_EPS,
@@ -96,3 +103,96 @@ class HumanoidMPCUnknownEnvironment(HumanoidMPC):
         rings = [xy[j, :nv[j]].copy() for j in range(n)]
         self.list_inferred_obstacles.append(rings)
         return rings
+
+
+class UnknownEnvFleet:
+    """B robots walking through one map that they only see through their LiDAR: the closed loop of
+    HumanoidMPCUnknownEnvironment (HumanoidMpc.py:380-459 with _get_list_c_and_eta from
+    HumanoidMPCUnknownEnvironment.py:30-68) for a whole batch and without a host round trip per sample — scan, step
+    solve and state advance are enqueued back to back; with ``use_graph`` one sample is captured in a HIP graph and
+    replayed.  One MPC solve per sample (sampling_time = DELTA_T), the reference's stop rule (previous objective <
+    0.05) and stop-on-failed-solve per robot."""
+
+    def __init__(self, env_rings, N_horizon=3, lidar_range=3.0, resolution=360, n_obs_max=12, v_max=32,
+                 exact=False, device=None):
+        from .solver import BatchedLipMpc, LipMpcParams, FLAG_INTERIOR
+        self.sensor = LidarSensor(env_rings, lidar_range, resolution, n_obs_max, v_max, device)
+        self.solver = BatchedLipMpc(LipMpcParams(N=N_horizon, n_obs_max=n_obs_max, v_max=v_max,
+                                                 flags=0 if exact else FLAG_INTERIOR), self.sensor.device_index)
+        self.device = self.sensor.device
+
+    def run(self, state0, goal, first_foot, k_max, noise="seeded", noise_seed=0, delta=None, stop_obj=0.05,
+            use_graph=True):
+        """state0 [B,5], goal [B,2], first_foot [B] int8.  noise: "seeded" (N(0, 0.01) per reading from a generator
+        seeded with noise_seed), None (noiseless) or a tensor [k_max,B,resolution,2].  Returns dict(X_pred
+        [B,k_max+1,5], U_pred [B,k_max,3], n_steps [B] solved samples, last_status [B], overflow [B] samples whose
+        clusters did not fit the obstacle slots)."""
+        dev, sv, sn = self.device, self.solver, self.sensor
+        B = state0.shape[0]
+        state, foot = state0.clone(), first_foot.clone()
+        X = torch.zeros((B, k_max + 1, 5), dtype=torch.float64, device=dev)
+        U = torch.zeros((B, k_max, 3), dtype=torch.float64, device=dev)
+        X[:, 0] = state
+        alive = torch.ones((B,), dtype=torch.bool, device=dev)
+        last_obj = torch.full((B,), float("inf"), dtype=torch.float64, device=dev)
+        n_steps = torch.zeros((B,), dtype=torch.int32, device=dev)
+        last_status = torch.zeros((B,), dtype=torch.int32, device=dev)
+        n_overflow = torch.zeros((B,), dtype=torch.int32, device=dev)
+        u_k = torch.zeros((B, 3), dtype=torch.float64, device=dev)
+        sen = sn.alloc_outputs(B)
+        out = sv.alloc_outputs(B)
+        nbuf = None if noise is None else torch.zeros((B, sn.resolution, 2), dtype=torch.float64, device=dev)
+        gen = torch.Generator(device=dev).manual_seed(int(noise_seed)) if isinstance(noise, str) else None
+        nxt_state, nxt_foot = state.clone(), foot.clone()
+
+        def sample():
+            # HumanoidMpc.py:392 stop rule, :387/:417 sense + solve, :419-429 failed solve ends the run, :432-447 advance
+            alive.logical_and_(last_obj >= stop_obj)
+            sn.sense(state, nbuf, out=sen)
+            sv.plan_step_batch(state, goal, foot, sen["obs_xy"], sen["obs_nv"], delta, out=out)
+            ok = (out["status"] == 0) | (out["status"] == 4)
+            last_status.copy_(torch.where(alive, out["status"], last_status))
+            alive.logical_and_(ok)
+            last_obj.copy_(torch.where(alive, out["obj"], last_obj))
+            nxt_state.copy_(state); nxt_foot.copy_(foot)
+            sv.advance(nxt_state, nxt_foot, out)
+            state.copy_(torch.where(alive[:, None], nxt_state, state))
+            foot.copy_(torch.where(alive, nxt_foot, foot))
+            u_k[:, :2] = out["U"][:, 0]
+            u_k[:, 2] = out["omega"][:, 0]
+            n_steps.add_(alive.to(torch.int32))
+            n_overflow.add_(sen["overflow"] * alive.to(torch.int32))
+
+        def fill_noise(k):
+            if gen is not None:
+                nbuf.normal_(0.0, NOISE_STD, generator=gen)
+            elif nbuf is not None:
+                nbuf.copy_(noise[k])
+
+        graph = None
+        if use_graph:
+            fill_noise(0)
+            keep = [t.clone() for t in (state, foot, alive, last_obj, n_steps, last_status, n_overflow)]
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                sample()                                     # warm-up outside capture (allocator, lazy init)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            for t, c in zip((state, foot, alive, last_obj, n_steps, last_status, n_overflow), keep):
+                t.copy_(c)
+            if gen is not None:
+                gen.manual_seed(int(noise_seed))
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                sample()
+            for t, c in zip((state, foot, alive, last_obj, n_steps, last_status, n_overflow), keep):
+                t.copy_(c)
+        for k in range(k_max):
+            fill_noise(k)
+            if graph is not None:
+                graph.replay()
+            else:
+                sample()
+            U[:, k] = u_k
+            X[:, k + 1] = state
+        return dict(X_pred=X, U_pred=U, n_steps=n_steps, last_status=last_status, overflow=n_overflow)

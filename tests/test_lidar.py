@@ -162,3 +162,46 @@ def test_gpu_unknown_environment_class_and_throughput(golden_dir):
     print(f"config 5, B={B}: scan {e[0].elapsed_time(e[1]):.3f} ms + step {e[1].elapsed_time(e[2]):.3f} ms; "
           f"inferred obstacles mean {float(sen['n_inferred'].double().mean()):.2f}, overflow {int(sen['overflow'].sum())}")
     assert int(sen["overflow"].sum()) == 0
+
+
+@pytest.mark.gpu
+def test_gpu_unknown_environment_fleet_matches_class(golden_dir):
+    """UnknownEnvFleet (scan + solve + advance enqueued per sample, captured in a HIP graph) against the drop-in
+    class driven sample by sample from the host, on the same noise stream: identical trajectories; robots with
+    other noise / starts walk the same map in the same launches."""
+    torch = pytest.importorskip("torch")
+    import lipmpc
+    d = np.load(os.path.join(golden_dir, "lidar_golden.npz"))
+    _, rings, _ = _case(d, 0)
+    K = 25
+    mpc = lipmpc.HumanoidMPCUnknownEnvironment(goal=(5, 5), obstacles=rings, N_horizon=3, N_mpc_timesteps=K,
+                                               sampling_time=0.4, init_state=(-0.8, 0, -0.8, 0, 0.7), verbosity=0,
+                                               lidar_range=1.5, noise_seed=7)
+    X, U, _ = mpc.run_simulation(None, make_fast_plot=False, fill_animator=False)
+    # the class draws randn((1, 360, 2)) per sample from a generator seeded 7: rebuild that stream for robot 0
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    B = 4
+    noise = torch.zeros((K, B, 360, 2), dtype=torch.float64, device="cuda")
+    for k in range(K):
+        noise[k, 0] = 0.01 * torch.randn((1, 360, 2), dtype=torch.float64, device="cuda", generator=gen)[0]
+    noise[:, 1:] = 0.01 * torch.randn((K, B - 1, 360, 2), dtype=torch.float64, device="cuda")
+    st0 = torch.tensor([[-0.8, 0, -0.8, 0, 0.7]] * B, dtype=torch.float64, device="cuda")
+    st0[3, 0] = 5.5; st0[3, 2] = -0.5; st0[3, 4] = 2.0
+    goal = torch.tensor([[5.0, 5.0]] * B, dtype=torch.float64, device="cuda")
+    foot = torch.ones((B,), dtype=torch.int8, device="cuda")
+    res = {}
+    for use_graph in (False, True):
+        fleet = lipmpc.UnknownEnvFleet(rings, N_horizon=3, lidar_range=1.5)
+        r = fleet.run(st0, goal, foot, K, noise=noise, use_graph=use_graph)
+        torch.cuda.synchronize()
+        res[use_graph] = {k: v.cpu().numpy() for k, v in r.items()}
+    for use_graph in (False, True):
+        r = res[use_graph]
+        n0 = int(r["n_steps"][0])
+        kk = n0 if n0 < K else K - 1                    # the class's truncation (HumanoidMpc.py:457-459)
+        assert X.shape[1] == kk + 1, (X.shape, n0)
+        assert np.max(np.abs(r["X_pred"][0, :kk + 1].T - X)) < 1e-9
+        assert np.max(np.abs(r["U_pred"][0, :kk].T - U)) < 1e-9
+        assert r["n_steps"].min() >= 5 and r["overflow"].sum() == 0
+    assert np.array_equal(res[False]["X_pred"], res[True]["X_pred"])
+    assert np.array_equal(res[False]["n_steps"], res[True]["n_steps"])
