@@ -29,6 +29,7 @@ constexpr int RMAX = 384;            // rays per scan (reference: 360)
 constexpr int WORDS = RMAX / 64;     // neighbour bit row
 constexpr int NO_ROOT = 0x7fffffff;
 constexpr int VSTAGE = 64;          // hull vertices staged per cluster (v_max <= VSTAGE)
+static_assert(4 * VSTAGE * 2 <= 2 * RMAX, "hull staging reuses the point arrays");
 
 struct Cand { double x, y; int idx; };
 
@@ -53,10 +54,12 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
     const int32_t* __restrict__ env_nv, const double* __restrict__ ray_table, const double* __restrict__ noise,
     double* __restrict__ obs_xy, int32_t* __restrict__ obs_nv, int32_t* __restrict__ n_inferred,
     int32_t* __restrict__ overflow, double* __restrict__ hits_out, int32_t* __restrict__ labels_out, int dbg_stop) {
-  __shared__ double px_[RMAX], py_[RMAX];
+  __shared__ double pxy_[2 * RMAX];
+  double* const px_ = pxy_;
+  double* const py_ = pxy_ + RMAX;
   __shared__ __attribute__((aligned(16))) int comp_[RMAX];                    // -1 = no reading; core: component root; else NO_ROOT
   __shared__ int root_[RMAX];                    // cluster root of every reading (NO_ROOT = noise)
-  __shared__ unsigned long long nb_[RMAX][WORDS];
+  __shared__ double cx_[RMAX], cy_[RMAX];       // points in member-list order (hull stage)
   __shared__ int roots_[64];
   __shared__ int cand_[RMAX];                    // obstacles that can be hit from here, list order
 
@@ -168,24 +171,34 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
     const int left = n_pts - w * 64;
     vmask[w] = left >= 64 ? ~0ull : (left <= 0 ? 0ull : ((1ull << left) - 1ull));
   }
-  for (int i = lane; i < npad; i += 64) {
+  // row[k][w]: neighbour bits of point lane + 64 k against the 64 points of word w — kept in registers (the lane
+  // that computes a row is the only one that reads it), which keeps the LDS footprint at 19 KB = 8 waves per CU
+  unsigned long long row[WORDS][WORDS];
+#pragma unroll
+  for (int k = 0; k < WORDS; ++k) {
+#pragma unroll
+    for (int w = 0; w < WORDS; ++w) row[k][w] = 0ull;
+  }
+  for (int k = 0; k < NW; ++k) {
+    const int i = k * 64 + lane;
     int cnt = 0;
     const bool vi = comp_[i] >= 0;
     const double xi = px_[i], yi = py_[i];
 #pragma unroll
     for (int w = 0; w < WORDS; ++w) {
-      if (w >= NW) { nb_[i][w] = 0ull; continue; }
+      if (w >= NW) continue;
       // counted, unrolled sweep over all 64 slots of the word (loads pipeline; absent points are masked after)
       unsigned long long bits = 0ull;
 #pragma unroll 16
-      for (int k = 0; k < 64; ++k) {
+      for (int kk = 0; kk < 64; ++kk) {
 #pragma clang fp contract(off)
-        const double dx = xi - px_[w * 64 + k], dy = yi - py_[w * 64 + k];
-        bits |= (unsigned long long)(dx * dx + dy * dy <= eps2) << k;
+        const double dx = xi - px_[w * 64 + kk], dy = yi - py_[w * 64 + kk];
+        bits |= (unsigned long long)(dx * dx + dy * dy <= eps2) << kk;
       }
       bits = vi ? (bits & vmask[w]) : 0ull;
       cnt += __popcll(bits);
-      nb_[i][w] = bits;
+#pragma unroll
+      for (int k2 = 0; k2 < WORDS; ++k2) if (k2 == k) row[k2][w] = bits;     // k is wave-uniform
     }
     root_[i] = (vi && cnt >= min_samples) ? i : NO_ROOT;      // core points start as their own root
   }
@@ -205,12 +218,6 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
   unsigned long long cmask[WORDS];
 #pragma unroll
   for (int w = 0; w < WORDS; ++w) { const int cj = comp_[w * 64 + lane]; cmask[w] = __ballot(cj >= 0 && cj != NO_ROOT); }
-  unsigned long long row[WORDS][WORDS];             // row[k][w]: neighbour bits of point lane + 64 k, word w
-#pragma unroll
-  for (int k = 0; k < WORDS; ++k) {
-#pragma unroll
-    for (int w = 0; w < WORDS; ++w) row[k][w] = (k < NW && w < NW) ? nb_[k * 64 + lane][w] : 0ull;
-  }
 #pragma unroll
   for (int k = 0; k < WORDS; ++k) {
     if (k >= NW) continue;
@@ -325,9 +332,7 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
   const int nc = n_clusters < 64 ? n_clusters : 64;
   int* list_ = cand_;                                   // member lists, cluster after cluster (labels are written)
   int* coff_ = comp_;                                   // coff_[k] .. coff_[k+1]: members of cluster k
-  double* stage_ = reinterpret_cast<double*>(&nb_[0][0]);   // [4][VSTAGE][2]
-  double* cx_ = stage_ + 4 * VSTAGE * 2;                  // points in member-list order (direct, pipelined reads)
-  double* cy_ = cx_ + RMAX;
+  double* stage_ = pxy_;                                // [4][VSTAGE][2]: the points live on in cx_/cy_ from here
   __syncthreads();
   {
     int off = 0;
