@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_$1
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -- python3 $R/bench.py --no-cpu-baseline > $O/bench_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py --no-cpu-baseline > $O/bench_stats.log 2>&1
 find /tmp/prof_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 python3 - "$O" <<'PY'
 import csv, glob, sys
@@ -23,7 +23,7 @@ rm -rf /tmp/prof_stats
 echo "counter,mean_per_launch_over_the_10_timed_launches" > $O/pmc.csv
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
   rm -rf /tmp/prof_pmc
-  rocprofv3 --kernel-trace --pmc $c -d /tmp/prof_pmc -- python3 $R/bench.py --no-cpu-baseline --steps 10 --warmup 2 > $O/bench_pmc.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/prof_pmc -- python3 $R/bench.py --no-cpu-baseline --steps 10 --warmup 2 > $O/bench_pmc.log 2>&1
   python3 - "$O" <<'PY'
 import csv, glob, sys, collections
 O = sys.argv[1]
