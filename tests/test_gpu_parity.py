@@ -75,7 +75,7 @@ def test_smoke_single_problem_no_obstacles():
     assert s["worst_u"] < 1e-8
 
 
-@pytest.mark.parametrize("N,n_obs,ntraj,steps", [(3, 3, 6, 25), (5, 3, 4, 20), (8, 10, 6, 25), (8, 13, 4, 20)])
+@pytest.mark.parametrize("N,n_obs,ntraj,steps", [(3, 3, 6, 25), (5, 3, 4, 20), (8, 10, 6, 25), (8, 13, 4, 20), (10, 12, 5, 14)])
 def test_closed_loop_states_match_oracle(N, n_obs, ntraj, steps):
     probs = list(closed_loop_problems(N, n_obs, ntraj, steps, seed=100 + N))
     assert len(probs) > 50
@@ -339,11 +339,14 @@ def _rollout_inputs(n_robots, n_obs, seed):
     return st, goal, foot, xy, nv
 
 
-def test_rollout_equals_host_driven_loop():
+@pytest.mark.parametrize("N,n_obs", [(8, 10), (8, 12), (12, 12), (8, 20)])
+def test_rollout_equals_host_driven_loop(N, n_obs):
     """lipmpc_rollout_batch (whole closed loop in one launch) against the same loop driven from the host
     with plan_step_batch + advance_batch: same step code, so the first samples agree to rounding and
-    the runs have the same structure (the loop is chaotic afterwards: LDCBF normals amplify 1e-16)."""
-    B, K, N, n_obs = 64, 40, 8, 10
+    the runs have the same structure (the loop is chaotic afterwards: LDCBF normals amplify 1e-16).
+    The parameter sets walk through the rollout instantiations: 5 and 7 register row slots per lane at 16 lanes,
+    7 at 32 lanes, 13 streamed rows."""
+    B, K = 64, 40
     st, goal, foot, xy, nv = _rollout_inputs(B, n_obs, 11)
     P = lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5, flags=lipmpc.FLAG_INTERIOR)
     sv = lipmpc.BatchedLipMpc(P)
@@ -370,10 +373,13 @@ def test_rollout_equals_host_driven_loop():
         Xh[:, k + 1] = s.cpu().numpy()
         nh += alive
     assert np.array_equal(nr, nh) or np.mean(np.abs(nr - nh) <= 2) > 0.9
+    # 16-lane groups: both kernels compile the step identically.  32-lane groups: the two kernels schedule (and
+    # contract) the step differently, the interior iterate moves in its last digits and the loop amplifies that
+    tol_x, tol_u, n_cmp = (1e-9, 1e-7, 8) if N <= 8 else (1e-5, 1e-5, 5)
     for b in range(B):
-        n = min(nr[b], nh[b], 8)
-        assert np.max(np.abs(Xr[b, : n + 1] - Xh[b, : n + 1])) < 1e-9, b
-        assert np.max(np.abs(Ur[b, :n] - Uh[b, :n])) < 1e-7, b
+        n = min(nr[b], nh[b], n_cmp)
+        assert np.max(np.abs(Xr[b, : n + 1] - Xh[b, : n + 1])) < tol_x, b
+        assert np.max(np.abs(Ur[b, :n] - Uh[b, :n])) < tol_u, b
     assert np.median(nr) >= 30          # robots actually walk
 
 
