@@ -880,12 +880,14 @@ __device__ __forceinline__ StepOut step_body(
 
   // diagnostics: identification margin min |log(z/(1e5 s))| and final mu of the interior-point phase;
   // initial working set z > 1e5 s
-  double marg_l = INFINITY, mufin_l = 0.0;
+  // (the logarithms cost ~2 us per wave: only when the caller asked for diag)
+  double marg_l = INFINITY;
+  const bool want_diag = diag != nullptr;
   bool act[NR];
   unsigned abits = 0u;
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
-    if (pres[i]) { marg_l = fmin(marg_l, fabs(log(z[i] / (FIN_IDENT * s[i])))); mufin_l += s[i] * z[i]; }
+    if (want_diag && pres[i]) marg_l = fmin(marg_l, fabs(log(z[i] / (FIN_IDENT * s[i]))));
     act[i] = pres[i] && (z[i] > FIN_IDENT * s[i]);
   }
   if constexpr (STREAM) {
@@ -893,15 +895,13 @@ __device__ __forceinline__ StepOut step_body(
     for (int t = 0; t < NOBS_S; ++t) {
       if ((pbits >> t) & 1u) {
         const double st = lds_sz[grp][t][lane][0], zt = lds_sz[grp][t][lane][1];
-        marg_l = fmin(marg_l, fabs(log(zt / (FIN_IDENT * st))));
-        mufin_l += st * zt;
+        if (want_diag) marg_l = fmin(marg_l, fabs(log(zt / (FIN_IDENT * st))));
         if (zt > FIN_IDENT * st) abits |= 1u << t;
       }
     }
   }
   const unsigned fbits = abits;          // fallback working set of an uncertified finish
   const double margin = gmin<G>(marg_l);
-  const double mu_fin = gsum<G>(mufin_l) / fmax(m_rows, 1.0);
   double diag_rounds = 0.0, diag_eres = 0.0, diag_cert = 0.0;
 
   // ---- certified active-set finish --------------------------------------------------------------
