@@ -284,12 +284,18 @@ def cpu_baseline(P, state, goal, foot, obs_xy, obs_nv, delta, out):
     U = out["U"].cpu().numpy()
     ok = (r1["status"] == 0) & (out["status"].cpu().numpy() == 0)
     du = float(np.max(np.abs(U[ok] - r1["U"][ok]))) if ok.any() else float("nan")
+    # active sets, bit for bit, on the certified problems whose certificate is decisive (margin >= 1e-6: a weakly
+    # active row may legitimately sit on either side)
+    act_g = out["active"].cpu().numpy().view(np.uint64)
+    firm = ok & (r1["diag"][:, 3] >= 1e-6)
+    act_mism = int(np.sum(np.any(act_g[firm] != r1["active"][firm], axis=1)))
     return {"value": done / t_all, "unit": "solves/s", "cores": cores, "kind": "port",
             "sample": f"the same {B}-problem batch x {reps} passes, OpenMP over problems ({cores} threads); "
                       f"single thread: {B / t1:.0f} solves/s",
             "value_1thread": B / t1,
             "max_abs_dU_gpu_vs_cpu": du,
-            "status_mismatches": int(np.sum(r1["status"] != out["status"].cpu().numpy()))}
+            "status_mismatches": int(np.sum(r1["status"] != out["status"].cpu().numpy())),
+            "active_set_mismatches": act_mism, "active_sets_compared": int(firm.sum())}
 
 
 if __name__ == "__main__":
