@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="problems per GPU")
     ap.add_argument("--horizon", type=int, default=8)
     ap.add_argument("--obstacles", type=int, default=10)
+    ap.add_argument("--finish-rounds", type=int, default=0, help="lipmpc_params.finish_rounds (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--all-configs", action="store_true",
                     help="also time BASELINE configs 4 (N=16, 50 obstacles) and 5 (LiDAR front end) as extras")
@@ -66,7 +67,7 @@ def main():
     N, n_obs, B = args.horizon, args.obstacles, args.batch
     hi = 9.5 if N <= 8 else 15.5
     goal_xy = (10.0, 10.0) if N <= 8 else (16.0, 16.0)
-    P = lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5)
+    P = lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5, finish_rounds=args.finish_rounds)
     solver = lipmpc.BatchedLipMpc(P, local_rank)
     walker = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5, flags=lipmpc.FLAG_INTERIOR), local_rank)
 

@@ -11,7 +11,7 @@ class LipmpcParamsC(C.Structure):
     """struct lipmpc_params (include/lipmpc.h)"""
     _fields_ = [
         ("N", C.c_int32), ("n_obs_max", C.c_int32), ("v_max", C.c_int32), ("max_iter", C.c_int32),
-        ("flags", C.c_int32), ("reserved", C.c_int32),
+        ("flags", C.c_int32), ("finish_rounds", C.c_int32),
         ("dt", C.c_double), ("g", C.c_double), ("h_com", C.c_double), ("alpha", C.c_double),
         ("l_max", C.c_double * 2), ("l_min", C.c_double * 2), ("v_min", C.c_double * 2),
         ("v_max_xy", C.c_double * 2),

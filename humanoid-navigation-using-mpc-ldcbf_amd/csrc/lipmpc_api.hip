@@ -42,7 +42,7 @@ extern "C" {
 int lipmpc_default_params(lipmpc_params* p) {
   if (!p) return LIPMPC_E_ARG;
   memset(p, 0, sizeof(*p));
-  p->N = 3; p->n_obs_max = 0; p->v_max = 5; p->max_iter = 60; p->flags = 0;
+  p->N = 3; p->n_obs_max = 0; p->v_max = 5; p->max_iter = 60; p->flags = 0; p->finish_rounds = 0;
   p->dt = 0.4; p->g = 9.81; p->h_com = 1.0; p->alpha = 3.6;
   p->l_max[0] = 0.10; p->l_max[1] = 0.10; p->l_min[0] = -0.1; p->l_min[1] = -0.1;
   p->v_min[0] = -0.1; p->v_min[1] = 0.1; p->v_max_xy[0] = 0.8; p->v_max_xy[1] = 0.4;
@@ -57,7 +57,7 @@ int64_t lipmpc_active_words(const lipmpc_params* p) { return p ? (lipmpc_num_row
 int lipmpc_create(const lipmpc_params* p, int device, lipmpc_handle** out) {
   if (!p || !out) return LIPMPC_E_ARG;
   if (p->N < 1 || p->N > 16 || p->n_obs_max < 0 || p->n_obs_max > 50 || p->v_max < 3 || p->v_max > 32 ||
-      p->max_iter < 1 || !(p->tol > 0.0) || !(p->tol_interior > 0.0) || !(p->dt > 0.0) || !(p->h_com > 0.0) || !(p->g > 0.0))
+      p->max_iter < 1 || p->finish_rounds < 0 || p->finish_rounds > 64 || !(p->tol > 0.0) || !(p->tol_interior > 0.0) || !(p->dt > 0.0) || !(p->h_com > 0.0) || !(p->g > 0.0))
     return LIPMPC_E_UNSUPPORTED;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return LIPMPC_E_HIP;
@@ -70,6 +70,7 @@ int lipmpc_create(const lipmpc_params* p, int device, lipmpc_handle** out) {
   h->nobs_l = need == 0 ? 0 : need <= 2 ? 2 : need <= 5 ? 5 : need <= 7 ? 7 : need <= 13 ? 13 : 25;
   KArgs& k = h->k;
   k.N = p->N; k.n_obs = p->n_obs_max; k.nvert_max = p->v_max; k.max_iter = p->max_iter; k.flags = p->flags;
+  k.fin_rounds = p->finish_rounds > 0 ? p->finish_rounds : FIN_ROUNDS;
   k.m_tot = (int)lipmpc_num_rows(p); k.words = (int)lipmpc_active_words(p);
   const double beta = sqrt(p->g / p->h_com), ch = cosh(beta * p->dt), sh = sinh(beta * p->dt);
   k.kappa = beta * sh / (ch - 1.0); k.ch = ch; k.sh_over_beta = sh / beta; k.inv_one_minus_ch = 1.0 / (1.0 - ch);

@@ -41,15 +41,17 @@ constexpr double IPM_Z0 = 30.0;
 constexpr double IPM_STEP_FRAC = 0.995;
 constexpr double IPM_Z_DIVERGE = 1e13;
 constexpr double IPM_STALL_TOL = 1e-6;   // factorisation breakdown below this (r_p, mu) counts as converged
+constexpr int IPM_SLOW_FROM = 8;
+constexpr double IPM_SLOW_RATIO = 0.9, IPM_SLOW_SIGMA = 0.5;   // no progress in mu (from iteration 8 on) -> centre up to half way
 constexpr double FIN_RHO = 1e10;
 constexpr double FIN_EPS = 1e-9;
-constexpr int FIN_ROUNDS = 10;
+constexpr int FIN_ROUNDS = 5;            // default of lipmpc_params.finish_rounds (tail latency: see DESIGN.md)
 constexpr double FIN_IDENT = 1e5;   // initial working set z > FIN_IDENT * s: a deliberate under-estimate (oracle docstring)
 constexpr int FIN_INNER = 6;
 constexpr double FIN_INNER_TOL = 1e-11;
 
 struct KArgs {
-  int N, n_obs, nvert_max, max_iter, flags;
+  int N, n_obs, nvert_max, max_iter, flags, fin_rounds;
   int m_tot, words;
   double kappa, ch, sh_over_beta, inv_one_minus_ch, beta_sh;
   double l_max[2], l_min[2], v_min[2], v_max[2];
@@ -708,6 +710,7 @@ __device__ __forceinline__ StepOut step_body(
 
   // Groups of a wave leave the loop independently (real divergence: a finished group's lanes are
   // simply masked off; all exchanges inside are row-local DPP / group-local LDS).
+  double mu_prev = INFINITY;
   for (int it = 0; it <= P.max_iter; ++it) {
     if (__all(done)) break;
     if (!done) {
@@ -796,7 +799,13 @@ __device__ __forceinline__ StepOut step_body(
         const double a_aff = 1.0 / gmax<G>(r_l);
         const double mu_aff = fma(a_aff, fma(a_aff, gsum<G>(s2_l), gsum<G>(s1_l)), musum) / m_rows;
         const double ratio = mu_aff / mu;
-        const double sigma_mu = ratio * ratio * ratio * mu;
+        double sigma = ratio * ratio * ratio;
+        if (it >= IPM_SLOW_FROM) {      // no-progress safeguard, a ramp in mu / mu_prev (oracle/lipmpc_oracle.py)
+          const double ramp = fmin(1.0, fmax(0.0, (mu / mu_prev - IPM_SLOW_RATIO) * (1.0 / (1.0 - IPM_SLOW_RATIO))));
+          sigma = fmax(sigma, IPM_SLOW_SIGMA * ramp);
+        }
+        mu_prev = mu;
+        const double sigma_mu = sigma * mu;
         // corrector: rc = s z + ds_a dz_a - sigma mu
         double rc[NR];
 #pragma unroll
@@ -918,7 +927,7 @@ __device__ __forceinline__ StepOut step_body(
       for (int t = 0; t < NOBS_S; ++t)
         if (!((abits >> t) & 1u)) lds_sz[grp][t][lane][1] = 0.0;
     }
-    for (int rnd = 0; rnd < FIN_ROUNDS; ++rnd) {
+    for (int rnd = 0; rnd < P.fin_rounds; ++rnd) {
       if (__all(fin_done)) break;
       double d[NR];
 #pragma unroll

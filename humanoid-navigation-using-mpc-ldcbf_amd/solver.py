@@ -23,6 +23,7 @@ class LipMpcParams:
     n_obs_max: int = 0
     v_max: int = 5
     max_iter: int = 60
+    finish_rounds: int = 0      # 0 = library default (5 add/drop rounds)
     flags: int = 0
     dt: float = 0.4
     g: float = 9.81
@@ -41,7 +42,7 @@ class LipMpcParams:
 
     def to_c(self):
         p = _lib.LipmpcParamsC()
-        for f in ("N", "n_obs_max", "v_max", "max_iter", "flags"):
+        for f in ("N", "n_obs_max", "v_max", "max_iter", "flags", "finish_rounds"):
             setattr(p, f, int(getattr(self, f)))
         for f in ("dt", "g", "h_com", "alpha", "omega_max", "ell", "sampling_time", "tol", "tol_interior", "k0_tol"):
             setattr(p, f, float(getattr(self, f)))

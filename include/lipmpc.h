@@ -55,7 +55,8 @@ typedef struct lipmpc_params {
   int32_t v_max;        /* vertex slots per obstacle ring, 3..32 */
   int32_t max_iter;     /* interior-point iteration cap */
   int32_t flags;        /* LIPMPC_FLAG_* */
-  int32_t reserved;
+  int32_t finish_rounds; /* cap on the add/drop rounds of the certified active-set finish (tail-latency control:
+                           a problem that needs more ends UNCERTIFIED with the interior-point answer); 0 = default (5) */
   double dt;            /* DELTA_T            config.yml:2  */
   double g;             /* GRAVITY_CONST      config.yml:3  */
   double h_com;         /* COM_HEIGHT         config.yml:4  */

@@ -35,8 +35,10 @@
 
 static const double IPM_S_FLOOR = 0.1, IPM_Z0 = 30.0, IPM_STEP_FRAC = 0.995, IPM_Z_DIVERGE = 1e13;
 static const double IPM_STALL_TOL = 1e-6;
+static const int IPM_SLOW_FROM = 8;
+static const double IPM_SLOW_RATIO = 0.9, IPM_SLOW_SIGMA = 0.5;   /* no-progress safeguard, see lipmpc_oracle.py */
 static const double FIN_RHO = 1e10, FIN_EPS = 1e-9, FIN_INNER_TOL = 1e-11, FIN_IDENT = 1e5;
-enum { FIN_ROUNDS = 10, FIN_INNER = 6 };
+enum { FIN_ROUNDS = 5, FIN_INNER = 6 };
 
 /* ---- geometry (ObstaclesUtils.py:50-109) ------------------------------------------------ */
 static void closest_point_normal(const double* ring, int nv, double px, double py, double* cx, double* cy,
@@ -278,7 +280,7 @@ static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, cons
   mat_vec(G, q, m, n, t);
   for (int i = 0; i < m; ++i) { s[i] = fmax(h[i] - t[i], IPM_S_FLOOR); z[i] = IPM_Z0; }
   int status = LIPMPC_STATUS_MAX_ITER, it = 0;
-  double mu = 0.0;
+  double mu = 0.0, mu_prev = INFINITY;
   const double tol = (P->flags & LIPMPC_FLAG_INTERIOR) ? P->tol_interior : P->tol;
   for (it = 0; it <= P->max_iter; ++it) {
     mat_vec(G, q, m, n, t);
@@ -314,7 +316,13 @@ static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, cons
     double mu_aff = 0.0;
     for (int i = 0; i < m; ++i) mu_aff += (s[i] + a_aff * dsa[i]) * (z[i] + a_aff * dza[i]);
     mu_aff /= m;
-    double ratio = mu_aff / mu, sigma_mu = ratio * ratio * ratio * mu;
+    double ratio = mu_aff / mu, sigma = ratio * ratio * ratio;
+    if (it >= IPM_SLOW_FROM) {
+      double ramp = fmin(1.0, fmax(0.0, (mu / mu_prev - IPM_SLOW_RATIO) * (1.0 / (1.0 - IPM_SLOW_RATIO))));
+      sigma = fmax(sigma, IPM_SLOW_SIGMA * ramp);
+    }
+    mu_prev = mu;
+    double sigma_mu = sigma * mu;
     for (int i = 0; i < m; ++i) { rc[i] = s[i] * z[i] + dsa[i] * dza[i] - sigma_mu; w[i] = (z[i] * rp[i] - rc[i]) / s[i]; }
     matT_vec(G, w, m, n, tmp);
     for (int i = 0; i < n; ++i) dq[i] = -rd[i] - tmp[i];
@@ -342,7 +350,8 @@ static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, cons
     for (int i = 0; i < m; ++i) y[i] = act[i] ? z[i] : 0.0;
     int certified = 0, rounds = 0;
     double eres = INFINITY;
-    for (int rnd = 1; rnd <= FIN_ROUNDS; ++rnd) {
+    const int fin_rounds = P->finish_rounds > 0 ? P->finish_rounds : FIN_ROUNDS;
+    for (int rnd = 1; rnd <= fin_rounds; ++rnd) {
       rounds = rnd;
       for (int i = 0; i < m; ++i) d[i] = act[i] ? FIN_RHO : 0.0;
       form_K(G, d, m, n, K);

@@ -62,6 +62,7 @@ class Params:
     tol: float = 1e-11
     tol_interior: float = 1e-9      # stop tolerance of the interior (non-finished) mode, see include/lipmpc.h
     max_iter: int = 60
+    finish_rounds: int = 0      # 0 = FIN_ROUNDS
     k0_tol: float = 1e-5            # tolerated violation of the constant k=0 LDCBF rows
                                     # (= the reference's IPOPT constr_viol_tol, HumanoidMpc.py:99)
 
@@ -340,9 +341,13 @@ IPM_Z0 = 30.0          # initial multiplier
 IPM_STEP_FRAC = 0.995  # fraction to the boundary
 IPM_Z_DIVERGE = 1e13   # multiplier blow-up => infeasible
 IPM_STALL_TOL = 1e-6   # Cholesky breakdown below this (r_p, mu) counts as converged
+IPM_SLOW_FROM = 8      # from this iteration on (earlier, mu legitimately stalls while infeasibility is traded in):
+IPM_SLOW_RATIO = 0.9   # mu / previous mu between 0.9 and 1 = the iteration made (almost) no progress ...
+IPM_SLOW_SIGMA = 0.5   # ... then centre at least 0 .. this much, linearly (breaks the limit cycles of plain Mehrotra steps;
+                       # a ramp, not a switch: a threshold would let two implementations part ways on a rounding)
 FIN_RHO = 1e10         # penalty of the active-set equality solve
 FIN_EPS = 1e-9         # sign / violation threshold of the certificate
-FIN_ROUNDS = 10        # max add/drop rounds
+FIN_ROUNDS = 5         # default cap on add/drop rounds (Params.finish_rounds = 0)
 FIN_IDENT = 1e5        # initial working set: z_i > FIN_IDENT * s_i (see finish_active_set)
 FIN_INNER = 6          # max multiplier iterations per equality solve
 FIN_INNER_TOL = 1e-11
@@ -351,7 +356,8 @@ FIN_INNER_TOL = 1e-11
 def solve_qp_ipm(G, h, g, q0, tol=1e-11, max_iter=60):
     """min |q-g|^2 s.t. G q <= h by Mehrotra predictor-corrector on the normal equations
     K = 2I + G^T diag(z/s) G (slack form G q + s = h, s,z > 0).  Start: q0 (the caller passes
-    "stand still", p_k = p_0), s = max(h - G q0, 0.1), z = 30.  Stop when max|r_p| <= tol and
+    "stand still", p_k = p_0), s = max(h - G q0, 0.1), z = 30; sigma = (mu_aff/mu)^3, raised towards 0.5 after an
+    iteration (from the 8th on) that left mu above 0.9 of its previous value (linear ramp up to ratio 1).  Stop when max|r_p| <= tol and
     mu = s.z/m <= tol.  The dual residual is not part of the test: on the normal equations it
     stalls near cond(K)*eps, and the active-set finish below recomputes q exactly anyway."""
     m, n = G.shape
@@ -362,6 +368,7 @@ def solve_qp_ipm(G, h, g, q0, tol=1e-11, max_iter=60):
     z = np.full(m, IPM_Z0)
     status = STATUS_MAX_ITER
     it = 0
+    mu_prev = math.inf
     for it in range(max_iter + 1):
         rd = 2.0 * (q - g) + G.T @ z
         rp = G @ q + s - h
@@ -398,6 +405,13 @@ def solve_qp_ipm(G, h, g, q0, tol=1e-11, max_iter=60):
         a_aff = min(1.0, _max_step(s, ds_a), _max_step(z, dz_a))
         mu_aff = float((s + a_aff * ds_a) @ (z + a_aff * dz_a)) / m
         sigma = (mu_aff / mu) ** 3
+        # Safeguard: plain Mehrotra steps can fall into a limit cycle (two complementarity pairs trading places,
+        # mu constant, steps of 0.6) — seen once per ~4000 problems on LiDAR-inferred obstacle sets.  An iteration
+        # that did not reduce mu by 10 % is followed by one that centres at least half way.
+        if it >= IPM_SLOW_FROM:
+            ramp = min(1.0, max(0.0, (mu / mu_prev - IPM_SLOW_RATIO) * (1.0 / (1.0 - IPM_SLOW_RATIO))))
+            sigma = max(sigma, IPM_SLOW_SIGMA * ramp)
+        mu_prev = mu
         dq, ds, dz = kkt_solve(s * z + ds_a * dz_a - sigma * mu)
         a = min(1.0, IPM_STEP_FRAC * min(_max_step(s, ds), _max_step(z, dz)))
         q = q + a * dq
@@ -441,7 +455,7 @@ def eqp_multiplier_method(G, h, g, active, q, y_full):
     return q, y, res
 
 
-def finish_active_set(G, h, g, res: QPResult):
+def finish_active_set(G, h, g, res: QPResult, rounds_cap: int = 0):
     """Turn the interior-point estimate into the exact minimiser with a KKT certificate.
     Working set A <- {i : z_i > 1e5 s_i}; solve the equality-constrained problem on A; if some
     multiplier is < -1e-9 drop the most negative one, else if some row outside A is violated
@@ -456,7 +470,8 @@ def finish_active_set(G, h, g, res: QPResult):
     nz = np.any(G != 0.0, axis=1)
     A = (res.z > FIN_IDENT * res.s) & nz
     q, yf = res.q, np.where(A, res.z, 0.0)
-    for rnd in range(1, FIN_ROUNDS + 1):
+    cap = rounds_cap if rounds_cap > 0 else FIN_ROUNDS
+    for rnd in range(1, cap + 1):
         q, y, eres = eqp_multiplier_method(G, h, g, A, q, yf)
         yf = np.zeros(m); yf[A] = y
         slack = h - G @ q
@@ -474,10 +489,10 @@ def finish_active_set(G, h, g, res: QPResult):
                        float(np.min(slack[~A & nz])) if (~A & nz).any() else math.inf)
             return q, yf, slack, A, rnd, cert
         break
-    return q, yf, None, A, FIN_ROUNDS, None
+    return q, yf, None, A, cap, None
 
 
-def solve_qp_exact(G, h, g, q0, tol=1e-11, max_iter=60):
+def solve_qp_exact(G, h, g, q0, tol=1e-11, max_iter=60, finish_rounds=0):
     """IPM, then the certified active-set finish.  status 4 = IPM converged but the finish did
     not certify within its round budget (the IPM point is returned)."""
     res = solve_qp_ipm(G, h, g, q0, tol=tol, max_iter=max_iter)
@@ -488,7 +503,7 @@ def solve_qp_exact(G, h, g, q0, tol=1e-11, max_iter=60):
     with np.errstate(divide="ignore"):
         lr = np.abs(np.log(res.z[nz] / (FIN_IDENT * res.s[nz])))
     res.margin = float(np.min(lr)) if lr.size else math.inf
-    q, y, slack, A, rounds, cert = finish_active_set(G, h, g, res)
+    q, y, slack, A, rounds, cert = finish_active_set(G, h, g, res, finish_rounds)
     res.rounds = rounds
     res.cert_margin = cert if cert is not None else 0.0
     if cert is not None:
@@ -601,7 +616,7 @@ def plan_step(state, goal, first_foot, obstacles, delta, P: Params, exact=True):
     keep[k0] = False
     Gs, hs = G[keep], h[keep]
     q0 = np.tile([x0[0], x0[2]], N)
-    res = solve_qp_exact(Gs, hs, g, q0, tol=P.tol, max_iter=P.max_iter) if exact else \
+    res = solve_qp_exact(Gs, hs, g, q0, tol=P.tol, max_iter=P.max_iter, finish_rounds=P.finish_rounds) if exact else \
         solve_qp_ipm(Gs, hs, g, q0, tol=P.tol_interior, max_iter=P.max_iter)
     out["status"], out["iters"], out["rounds"] = res.status, res.iters, res.rounds
     if res.status not in (STATUS_SOLVED, STATUS_UNCERTIFIED):
