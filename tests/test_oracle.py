@@ -124,3 +124,21 @@ def test_status_codes():
     # no obstacles at all
     r = O.plan_step(np.array([0.0, 0, 0.0, 0, 0.0]), (5, 5), 1, [], 0.0, P)
     assert r["status"] == O.STATUS_SOLVED and r["active"].shape == (27,)
+
+
+def test_limit_cycle_case_converges(golden_dir):
+    """A step (found among 4096 LiDAR-inferred obstacle sets, N=3, one 10-vertex hull 0.29 m away) on which plain
+    Mehrotra steps fall into a 2-cycle (mu 4.26e-5 <-> 4.41e-5, steps of 0.6) and run into the iteration cap.  The
+    no-progress safeguard (IPM_SLOW_*) must get it to the optimum in a normal number of iterations; without the
+    safeguard the same code needs all 60."""
+    d = np.load(os.path.join(golden_dir, "limit_cycle_case.npz"))
+    P = O.Params(N=3)
+    r = O.plan_step(d["state"], d["goal"], 1, [d["ring0"]], 0.0, P, exact=True)
+    assert r["status"] == O.STATUS_SOLVED and r["iters"] <= 20, (r["status"], r["iters"])
+    saved = O.IPM_SLOW_SIGMA
+    try:
+        O.IPM_SLOW_SIGMA = 0.0                      # safeguard off: the cycle is back
+        r0 = O.plan_step(d["state"], d["goal"], 1, [d["ring0"]], 0.0, P, exact=True)
+    finally:
+        O.IPM_SLOW_SIGMA = saved
+    assert r0["status"] == O.STATUS_MAX_ITER and r0["iters"] == P.max_iter
