@@ -313,6 +313,7 @@ __device__ __forceinline__ StepOut step_body(
   __shared__ double lds_P[GPW][NMAX][2][2];                     // P_b blocks of the velocity part of K
   __shared__ unsigned long long lds_act[GPW][MAXWORDS];
   __shared__ int lds_flag[GPW];
+  __shared__ double lds_mu[GPW][2];      // no-progress safeguard: mu of the previous iteration, sigma floor of this one
   __shared__ double lds_sz[GPW][NOBS_S > 0 ? NOBS_S : 1][G][2];   // streamed rows: (s, z) then (s, y); lane-contiguous
 
   const int tid = threadIdx.x;
@@ -710,7 +711,7 @@ __device__ __forceinline__ StepOut step_body(
 
   // Groups of a wave leave the loop independently (real divergence: a finished group's lanes are
   // simply masked off; all exchanges inside are row-local DPP / group-local LDS).
-  double mu_prev = INFINITY;
+  if (lane == 0) { lds_mu[grp][0] = INFINITY; lds_mu[grp][1] = 0.0; }
   for (int it = 0; it <= P.max_iter; ++it) {
     if (__all(done)) break;
     if (!done) {
@@ -741,6 +742,13 @@ __device__ __forceinline__ StepOut step_body(
       }
       const double musum = gsum<G>(mu_l);
       const double mu = musum / m_rows;
+      {   // no-progress safeguard, a ramp in mu / mu_prev (oracle/lipmpc_oracle.py).  Both values live in LDS: one more
+          // double kept in registers across the factorisation costs 5 % of the iteration in AGPR traffic.
+        const double mu_prev = lds_mu[grp][0];
+        // (hardware reciprocal seed, 4.5e-8: the ramp is continuous, so that is as good as a division here)
+        const double ramp = fmin(1.0, fmax(0.0, (mu * __builtin_amdgcn_rcp(mu_prev) - IPM_SLOW_RATIO) * (1.0 / (1.0 - IPM_SLOW_RATIO))));
+        if (lane == 0) { lds_mu[grp][0] = mu; lds_mu[grp][1] = (it >= IPM_SLOW_FROM) ? IPM_SLOW_SIGMA * ramp : 0.0; }
+      }
       const double rpmax = gmax<G>(rpmax_l);
       const double zq = gmax<G>(fmax(zmax_l * (1.0 / IPM_Z_DIVERGE), fabs(q) * 1e-300));   // >= 1: diverged
       const bool bad = !(zq < 1.0);
@@ -800,11 +808,7 @@ __device__ __forceinline__ StepOut step_body(
         const double mu_aff = fma(a_aff, fma(a_aff, gsum<G>(s2_l), gsum<G>(s1_l)), musum) / m_rows;
         const double ratio = mu_aff / mu;
         double sigma = ratio * ratio * ratio;
-        if (it >= IPM_SLOW_FROM) {      // no-progress safeguard, a ramp in mu / mu_prev (oracle/lipmpc_oracle.py)
-          const double ramp = fmin(1.0, fmax(0.0, (mu / mu_prev - IPM_SLOW_RATIO) * (1.0 / (1.0 - IPM_SLOW_RATIO))));
-          sigma = fmax(sigma, IPM_SLOW_SIGMA * ramp);
-        }
-        mu_prev = mu;
+        sigma = fmax(sigma, lds_mu[grp][1]);      // no-progress safeguard: floor computed at the top of the iteration
         const double sigma_mu = sigma * mu;
         // corrector: rc = s z + ds_a dz_a - sigma mu
         double rc[NR];
