@@ -299,6 +299,9 @@ def test_config4_horizon16_50_obstacles(golden_dir):
     same = res["status"] == ref["status"]
     print("cfg4 statuses gpu", np.bincount(res["status"], minlength=5), "oracle", np.bincount(ref["status"], minlength=5))
     assert same.mean() >= 0.95
+    # certified vs uncertified may differ on a few problems; solved-or-not must not (a factorisation variant that
+    # reported 3 % of this class INFEASIBLE once slipped through the 95 % bar above)
+    assert (np.isin(res["status"], (0, 4)) == np.isin(ref["status"], (0, 4))).mean() >= 0.98
     ok = same & (ref["status"] == 0)
     assert ok.sum() > 0.6 * len(probs)
     assert np.max(np.abs(res["U"][ok] - ref["U"][ok])) < 1e-5
