@@ -5,7 +5,7 @@ import lipmpc, c_oracle
 from importlib import import_module
 synth=import_module("humanoid-navigation-using-mpc-ldcbf_amd.synth")
 rng=np.random.default_rng(int(sys.argv[1]) if len(sys.argv)>1 else 0)
-for (N,n_obs,B) in [(8,10,8192),(3,3,8192),(5,6,4096),(8,13,4096),(12,10,2048),(12,13,1024),(16,30,512)]:
+for (N,n_obs,B) in [(8,10,8192),(3,3,8192),(5,6,4096),(8,13,4096),(12,10,2048),(12,13,1024),(16,30,512),(16,50,1024)]:
     xy,nv=synth.synthetic_fields(64,n_obs,0.5,9.5,(0,0),(10,10),seed=int(rng.integers(1e6)))
     idx=rng.integers(0,64,B); xy=xy[idx].copy(); nv=nv[idx].copy()
     nv[rng.random(nv.shape)<0.1]=0                                  # empty slots
