@@ -70,7 +70,7 @@ int lipmpc_create(const lipmpc_params* p, int device, lipmpc_handle** out) {
   h->nobs_l = need == 0 ? 0 : need <= 2 ? 2 : need <= 5 ? 5 : need <= 7 ? 7 : need <= 13 ? 13 : 25;
   KArgs& k = h->k;
   k.N = p->N; k.n_obs = p->n_obs_max; k.nvert_max = p->v_max; k.max_iter = p->max_iter; k.flags = p->flags;
-  k.fin_rounds = p->finish_rounds > 0 ? p->finish_rounds : FIN_ROUNDS;
+  k.fin_rounds = p->finish_rounds > 0 ? p->finish_rounds : (p->N <= 8 ? FIN_ROUNDS : FIN_ROUNDS_LONG);
   k.m_tot = (int)lipmpc_num_rows(p); k.words = (int)lipmpc_active_words(p);
   const double beta = sqrt(p->g / p->h_com), ch = cosh(beta * p->dt), sh = sinh(beta * p->dt);
   k.kappa = beta * sh / (ch - 1.0); k.ch = ch; k.sh_over_beta = sh / beta; k.inv_one_minus_ch = 1.0 / (1.0 - ch);

@@ -45,7 +45,8 @@ constexpr int IPM_SLOW_FROM = 8;
 constexpr double IPM_SLOW_RATIO = 0.9, IPM_SLOW_SIGMA = 0.5;   // no progress in mu (from iteration 8 on) -> centre up to half way
 constexpr double FIN_RHO = 1e10;
 constexpr double FIN_EPS = 1e-9;
-constexpr int FIN_ROUNDS = 5;            // default of lipmpc_params.finish_rounds (tail latency: see DESIGN.md)
+constexpr int FIN_ROUNDS = 5;            // default of lipmpc_params.finish_rounds for N <= 8 (tail latency: see DESIGN.md)
+constexpr int FIN_ROUNDS_LONG = 10;      // ... and for longer horizons (worse conditioned, more exchanges needed)
 constexpr double FIN_IDENT = 1e5;   // initial working set z > FIN_IDENT * s: a deliberate under-estimate (oracle docstring)
 constexpr int FIN_INNER = 6;
 constexpr double FIN_INNER_TOL = 1e-11;

@@ -23,7 +23,7 @@ class LipMpcParams:
     n_obs_max: int = 0
     v_max: int = 5
     max_iter: int = 60
-    finish_rounds: int = 0      # 0 = library default (5 add/drop rounds)
+    finish_rounds: int = 0      # 0 = library default (5 add/drop rounds for N <= 8, else 10)
     flags: int = 0
     dt: float = 0.4
     g: float = 9.81

@@ -56,7 +56,7 @@ typedef struct lipmpc_params {
   int32_t max_iter;     /* interior-point iteration cap */
   int32_t flags;        /* LIPMPC_FLAG_* */
   int32_t finish_rounds; /* cap on the add/drop rounds of the certified active-set finish (tail-latency control:
-                           a problem that needs more ends UNCERTIFIED with the interior-point answer); 0 = default (5) */
+                           a problem that needs more ends UNCERTIFIED with the interior-point answer); 0 = default (5 for N <= 8, else 10) */
   double dt;            /* DELTA_T            config.yml:2  */
   double g;             /* GRAVITY_CONST      config.yml:3  */
   double h_com;         /* COM_HEIGHT         config.yml:4  */

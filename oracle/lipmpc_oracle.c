@@ -38,7 +38,7 @@ static const double IPM_STALL_TOL = 1e-6;
 static const int IPM_SLOW_FROM = 8;
 static const double IPM_SLOW_RATIO = 0.9, IPM_SLOW_SIGMA = 0.5;   /* no-progress safeguard, see lipmpc_oracle.py */
 static const double FIN_RHO = 1e10, FIN_EPS = 1e-9, FIN_INNER_TOL = 1e-11, FIN_IDENT = 1e5;
-enum { FIN_ROUNDS = 5, FIN_INNER = 6 };
+enum { FIN_ROUNDS = 5, FIN_ROUNDS_LONG = 10, FIN_INNER = 6 };
 
 /* ---- geometry (ObstaclesUtils.py:50-109) ------------------------------------------------ */
 static void closest_point_normal(const double* ring, int nv, double px, double py, double* cx, double* cy,
@@ -350,7 +350,7 @@ static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, cons
     for (int i = 0; i < m; ++i) y[i] = act[i] ? z[i] : 0.0;
     int certified = 0, rounds = 0;
     double eres = INFINITY;
-    const int fin_rounds = P->finish_rounds > 0 ? P->finish_rounds : FIN_ROUNDS;
+    const int fin_rounds = P->finish_rounds > 0 ? P->finish_rounds : (P->N <= 8 ? FIN_ROUNDS : FIN_ROUNDS_LONG);
     for (int rnd = 1; rnd <= fin_rounds; ++rnd) {
       rounds = rnd;
       for (int i = 0; i < m; ++i) d[i] = act[i] ? FIN_RHO : 0.0;

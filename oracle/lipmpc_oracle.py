@@ -347,7 +347,8 @@ IPM_SLOW_SIGMA = 0.5   # ... then centre at least 0 .. this much, linearly (brea
                        # a ramp, not a switch: a threshold would let two implementations part ways on a rounding)
 FIN_RHO = 1e10         # penalty of the active-set equality solve
 FIN_EPS = 1e-9         # sign / violation threshold of the certificate
-FIN_ROUNDS = 5         # default cap on add/drop rounds (Params.finish_rounds = 0)
+FIN_ROUNDS = 5         # default cap on add/drop rounds (Params.finish_rounds = 0) for N <= 8
+FIN_ROUNDS_LONG = 10   # ... and for longer horizons
 FIN_IDENT = 1e5        # initial working set: z_i > FIN_IDENT * s_i (see finish_active_set)
 FIN_INNER = 6          # max multiplier iterations per equality solve
 FIN_INNER_TOL = 1e-11
@@ -616,7 +617,8 @@ def plan_step(state, goal, first_foot, obstacles, delta, P: Params, exact=True):
     keep[k0] = False
     Gs, hs = G[keep], h[keep]
     q0 = np.tile([x0[0], x0[2]], N)
-    res = solve_qp_exact(Gs, hs, g, q0, tol=P.tol, max_iter=P.max_iter, finish_rounds=P.finish_rounds) if exact else \
+    fin = P.finish_rounds if P.finish_rounds > 0 else (FIN_ROUNDS if N <= 8 else FIN_ROUNDS_LONG)
+    res = solve_qp_exact(Gs, hs, g, q0, tol=P.tol, max_iter=P.max_iter, finish_rounds=fin) if exact else \
         solve_qp_ipm(Gs, hs, g, q0, tol=P.tol_interior, max_iter=P.max_iter)
     out["status"], out["iters"], out["rounds"] = res.status, res.iters, res.rounds
     if res.status not in (STATUS_SOLVED, STATUS_UNCERTIFIED):
