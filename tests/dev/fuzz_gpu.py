@@ -1,6 +1,6 @@
 """Dev tool: fuzz the step kernel against the C oracle with arbitrary (mostly infeasible or odd) inputs."""
 import sys, os, numpy as np, torch, time
-ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'oracle'))
+ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'oracle'))
 import lipmpc, c_oracle
 from importlib import import_module
 synth=import_module("humanoid-navigation-using-mpc-ldcbf_amd.synth")

@@ -1,6 +1,6 @@
 """Dev tool: G=32 (N=12, 10 obstacles) statuses / iterations / finish rounds against the C oracle."""
 import sys, os, numpy as np, torch
-ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'oracle')); sys.path.insert(0,os.path.join(ROOT,'tests'))
+ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'oracle')); sys.path.insert(0,os.path.join(ROOT,'tests'))
 import lipmpc, c_oracle
 from helpers import closed_loop_problems
 N,n_obs=12,10
