@@ -226,8 +226,8 @@ def other_configs(lipmpc, synth, dev):
     foot = torch.ones((B,), dtype=torch.int8, device=dev)
     solver = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=12, v_max=32), dev.index)
     o = solver.alloc_outputs(B)
-    ms_scan = _time_ms(lambda: sensor.sense(state, noise))
-    sen = sensor.sense(state, noise)
+    sen = sensor.alloc_outputs(B)
+    ms_scan = _time_ms(lambda: sensor.sense(state, noise, out=sen))
     ms_step = _time_ms(lambda: solver.plan_step_batch(state, goal, foot, sen["obs_xy"], sen["obs_nv"], None, out=o))
     out["config5_lidar"] = {"batch": B, "ms_scan": ms_scan, "ms_step": ms_step,
                             "robot_steps_per_s": B / (ms_scan + ms_step) * 1e3,
