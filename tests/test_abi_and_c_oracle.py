@@ -93,6 +93,28 @@ def test_c_oracle_equals_numpy_oracle(N, n_obs):
         assert np.array_equal(act[b], r["active"])
 
 
+@pytest.mark.parametrize("cap", [1, 2])
+def test_finish_rounds_cap_c_oracle_equals_numpy_oracle(cap):
+    """lipmpc_params.finish_rounds reaches both oracles the same way (statuses, rounds and answers agree under a
+    tight cap, where part of the batch ends UNCERTIFIED with the interior-point answer)."""
+    N, n_obs = 8, 10
+    probs = list(closed_loop_problems(N, n_obs, 3, 12, seed=77))
+    P = lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5, finish_rounds=cap)
+    xy, nv = lipmpc.pack_rings([p[3] for p in probs], n_obs, 5)
+    out = c_oracle.plan_step_batch(P, np.array([p[0] for p in probs]), np.array([p[1] for p in probs], float),
+                                   np.array([p[2] for p in probs], np.int8), xy, nv,
+                                   np.array([p[4] for p in probs], float), n_threads=2)
+    n4 = 0
+    for b, (st, goal, s0, obs, delta) in enumerate(probs):
+        r = O.plan_step(st, goal, s0, obs, delta, O.Params(N=N, finish_rounds=cap))
+        assert r["status"] == out["status"][b]
+        if r["status"] in (O.STATUS_SOLVED, O.STATUS_UNCERTIFIED):
+            assert r["rounds"] <= cap and out["diag"][b, 0] == r["rounds"]
+            assert np.max(np.abs(out["U"][b] - r["U"])) < 1e-8
+            n4 += r["status"] == O.STATUS_UNCERTIFIED
+    assert cap > 1 or n4 > 0
+
+
 def test_c_oracle_geometry_against_reference_golden(golden_dir):
     d = np.load(os.path.join(golden_dir, "geometry_golden.npz"))
     B = len(d["pts"])
