@@ -61,6 +61,7 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
   __shared__ int root_[RMAX];                    // cluster root of every reading (NO_ROOT = noise)
   __shared__ double cx_[RMAX], cy_[RMAX];       // points in member-list order (hull stage)
   __shared__ int roots_[64];
+  __shared__ double bb_[WORDS][4];               // bounding box (x0, x1, y0, y1) of the 64 points of each word
   __shared__ int cand_[RMAX];                    // obstacles that can be hit from here, list order
 
   const int lane = threadIdx.x;
@@ -179,14 +180,30 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
 #pragma unroll
     for (int w = 0; w < WORDS; ++w) row[k][w] = 0ull;
   }
+  // bounding boxes of the words: two words whose boxes are more than eps apart along an axis hold no neighbour pair,
+  // and the whole 64 x 64 block is skipped by the wave (clusters are contiguous runs of rays, so most off-diagonal
+  // blocks go)
+  for (int w = 0; w < NW; ++w) {
+    const int i = w * 64 + lane;
+    const bool vi = comp_[i] >= 0;
+    double x0 = vi ? px_[i] : INFINITY, x1 = vi ? px_[i] : -INFINITY, y0 = vi ? py_[i] : INFINITY, y1 = vi ? py_[i] : -INFINITY;
+    for (int m = 1; m < 64; m <<= 1) {
+      x0 = fmin(x0, __shfl_xor(x0, m, 64)); x1 = fmax(x1, __shfl_xor(x1, m, 64));
+      y0 = fmin(y0, __shfl_xor(y0, m, 64)); y1 = fmax(y1, __shfl_xor(y1, m, 64));
+    }
+    if (lane == 0) { bb_[w][0] = x0; bb_[w][1] = x1; bb_[w][2] = y0; bb_[w][3] = y1; }
+  }
+  __syncthreads();
   for (int k = 0; k < NW; ++k) {
     const int i = k * 64 + lane;
     int cnt = 0;
     const bool vi = comp_[i] >= 0;
     const double xi = px_[i], yi = py_[i];
+    const double kx0 = bb_[k][0], kx1 = bb_[k][1], ky0 = bb_[k][2], ky1 = bb_[k][3];
 #pragma unroll
     for (int w = 0; w < WORDS; ++w) {
       if (w >= NW) continue;
+      if (bb_[w][0] - kx1 > eps || kx0 - bb_[w][1] > eps || bb_[w][2] - ky1 > eps || ky0 - bb_[w][3] > eps) continue;   // wave-uniform
       // counted, unrolled sweep over all 64 slots of the word (loads pipeline; absent points are masked after)
       unsigned long long bits = 0ull;
 #pragma unroll 16
