@@ -28,6 +28,7 @@ namespace {
 constexpr int RMAX = 384;            // rays per scan (reference: 360)
 constexpr int WORDS = RMAX / 64;     // neighbour bit row
 constexpr int NO_ROOT = 0x7fffffff;
+constexpr int NCC = 64;             // candidates whose bounding circle is kept for the per-pass sector test
 constexpr int VSTAGE = 64;          // hull vertices staged per cluster (v_max <= VSTAGE)
 static_assert(4 * VSTAGE * 2 <= 2 * RMAX, "hull staging reuses the point arrays");
 
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
   __shared__ int root_[RMAX];                    // cluster root of every reading (NO_ROOT = noise)
   __shared__ double cx_[RMAX], cy_[RMAX];       // points in member-list order (hull stage)
   __shared__ int roots_[64];
+  __shared__ double candc_[NCC][3];              // bounding circle (centre, radius) of the first NCC candidate obstacles
   __shared__ double bb_[WORDS][4];               // bounding box (x0, x1, y0, y1) of the 64 points of each word
   __shared__ int cand_[RMAX];                    // obstacles that can be hit from here, list order
 
@@ -78,20 +80,23 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
   for (int j0 = 0; j0 < n_env; j0 += 64) {
     const int j = j0 + lane;
     bool keep = false;
+    double mx = 0.0, my = 0.0, rad = 0.0;
     if (j < n_env) {
       const int nv = env[j];
       const double* ring = exy + (long)j * v_env * 2;
-      double mx = 0.0, my = 0.0;
       for (int e = 0; e < nv; ++e) { mx += ring[2 * e]; my += ring[2 * e + 1]; }
       if (nv > 0) {
         mx /= nv; my /= nv;
-        double rad = 0.0;
         for (int e = 0; e < nv; ++e) rad = fmax(rad, hypot(ring[2 * e] - mx, ring[2 * e + 1] - my));
         keep = hypot(mx - x0, my - y0) <= (lidar_range + rad) * (1.0 + 1e-9) + 1e-9;
       }
     }
     const unsigned long long ball = __ballot(keep);
-    if (keep) { const int k = n_cand + __popcll(ball & ((1ull << lane) - 1ull)); if (k < RMAX) cand_[k] = j; }
+    if (keep) {
+      const int k = n_cand + __popcll(ball & ((1ull << lane) - 1ull));
+      if (k < RMAX) cand_[k] = j;
+      if (k < NCC) { candc_[k][0] = mx; candc_[k][1] = my; candc_[k][2] = rad; }
+    }
     n_cand += __popcll(ball);
   }
   __syncthreads();
@@ -103,7 +108,17 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
       const double ex = x0 + lidar_range * ray_table[2 * i], ey = y0 + lidar_range * ray_table[2 * i + 1];
       const double rdx = ex - x0, rdy = ey - y0;               // b1 - a1
       double best_d = lidar_range;
+      const double inv_len2 = __builtin_amdgcn_rcp(rdx * rdx + rdy * rdy);
       for (int jc = 0; jc < n_cand; ++jc) {
+        // sector test: the 64 rays of this pass span 64 degrees; an obstacle none of them comes near (distance from
+        // its bounding circle's centre to the ray segment > radius, with a margin far above the rounding of this
+        // estimate) is skipped by the whole wave — its edges could not have produced a hit for any of these rays
+        if (jc < NCC) {
+          const double wx = candc_[jc][0] - x0, wy = candc_[jc][1] - y0, cr = candc_[jc][2] + 1e-6;
+          const double tt = fmin(1.0, fmax(0.0, (wx * rdx + wy * rdy) * inv_len2));
+          const double ddx = wx - tt * rdx, ddy = wy - tt * rdy;
+          if (!__any(ddx * ddx + ddy * ddy <= cr * cr)) continue;
+        }
         const int j = cand_[jc];
         const int nv = env[j];
         const double* ring = exy + (long)j * v_env * 2;
