@@ -28,6 +28,7 @@ namespace {
 constexpr int RMAX = 384;            // rays per scan (reference: 360)
 constexpr int WORDS = RMAX / 64;     // neighbour bit row
 constexpr int NO_ROOT = 0x7fffffff;
+constexpr int SOLO_MIN = 48;        // a cluster of at least this many points gets the whole wave in the hull stage
 constexpr int NCC = 64;             // candidates whose bounding circle is kept for the per-pass sector test
 constexpr int VSTAGE = 64;          // hull vertices staged per cluster (v_max <= VSTAGE)
 static_assert(4 * VSTAGE * 2 <= 2 * RMAX, "hull staging reuses the point arrays");
@@ -392,31 +393,44 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
     { Cand o; o.x = lipmpc_dev::row_xor<4>(c.x); o.y = lipmpc_dev::row_xor<4>(c.y); o.idx = lipmpc_dev::row_xor<4>(c.idx); if (take_other(c, o)) c = o; }
     { Cand o; o.x = lipmpc_dev::row_xor<8>(c.x); o.y = lipmpc_dev::row_xor<8>(c.y); o.idx = lipmpc_dev::row_xor<8>(c.idx); if (take_other(c, o)) c = o; }
   };
-  for (int g = 0; g < nc; g += 4) {
-    const int k = g + q;
-    const bool on = k < nc;
+  auto wave_best = [&](Cand& c, auto&& take_other) {    // all 64 lanes: in-row DPP butterfly, then two cross-row steps
+    row_best(c, take_other);
+    { Cand o; o.x = __shfl_xor(c.x, 16, 64); o.y = __shfl_xor(c.y, 16, 64); o.idx = __shfl_xor(c.idx, 16, 64); if (take_other(c, o)) c = o; }
+    { Cand o; o.x = __shfl_xor(c.x, 32, 64); o.y = __shfl_xor(c.y, 32, 64); o.idx = __shfl_xor(c.idx, 32, 64); if (take_other(c, o)) c = o; }
+  };
+  // Clusters are processed in order.  A large cluster (a wall seen over many rays) gets the whole wave — its member
+  // scan is what a march step costs —, consecutive small ones share a wave, one per 16-lane row.
+  for (int g = 0; g < nc;) {
+    const bool solo = coff_[g + 1] - coff_[g] >= SOLO_MIN;            // wave-uniform
+    int ng = 1;
+    if (!solo) while (ng < 4 && g + ng < nc && coff_[g + ng + 1] - coff_[g + ng] < SOLO_MIN) ++ng;
+    const int W = solo ? 64 : 16;
+    const int lw = solo ? lane : l16, qrow = solo ? 0 : q;
+    const int k = g + qrow;
+    const bool on = qrow < ng;
     const int beg = on ? coff_[k] : 0, end = on ? coff_[k + 1] : 0;
     // lexicographically smallest point of the cluster
     Cand st; st.idx = -1; st.x = 0.0; st.y = 0.0;
-    for (int t = beg + l16; t < end; t += 16) {
+    for (int t = beg + lw; t < end; t += W) {
       const int i = list_[t];
       const double x = cx_[t], y = cy_[t];
       if (st.idx < 0 || x < st.x || (x == st.x && (y < st.y || (y == st.y && i < st.idx)))) { st.x = x; st.y = y; st.idx = i; }
     }
-    row_best(st, [](const Cand& a, const Cand& o) {
+    auto lex = [](const Cand& a, const Cand& o) {
       return o.idx >= 0 && (a.idx < 0 || o.x < a.x || (o.x == a.x && (o.y < a.y || (o.y == a.y && o.idx < a.idx))));
-    });
-    // Jarvis march of the four rows in lock step
+    };
+    if (solo) wave_best(st, lex); else row_best(st, lex);
+    // Jarvis march (of the rows in lock step)
     double cxp = st.x, cyp = st.y;
     int nvert = 0;
     bool done = !on;
     for (int step = 0; step <= v_max; ++step) {
       if (__all(done)) break;
-      if (!done && nvert < VSTAGE && l16 == 0) { stage_[(q * VSTAGE + nvert) * 2] = cxp; stage_[(q * VSTAGE + nvert) * 2 + 1] = cyp; }
+      if (!done && nvert < VSTAGE && lw == 0) { stage_[(qrow * VSTAGE + nvert) * 2] = cxp; stage_[(qrow * VSTAGE + nvert) * 2 + 1] = cyp; }
       if (!done) ++nvert;
       Cand best; best.idx = -1; best.x = 0.0; best.y = 0.0;
-      for (int t = beg + l16; t < end; t += 32) {               // two independent candidates per trip
-        const int t2 = t + 16;
+      for (int t = beg + lw; t < end; t += 2 * W) {               // two independent candidates per trip
+        const int t2 = t + W;
         const bool two = t2 < end;
         Cand c1, c2;
         c1.x = cx_[t]; c1.y = cy_[t]; c1.idx = list_[t];
@@ -424,7 +438,8 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
         if (!(c1.x == cxp && c1.y == cyp) && better(cxp, cyp, best, c1)) best = c1;
         if (two && !(c2.x == cxp && c2.y == cyp) && better(cxp, cyp, best, c2)) best = c2;
       }
-      row_best(best, [&](const Cand& a, const Cand& o) { return better(cxp, cyp, a, o); });
+      auto right = [&](const Cand& a, const Cand& o) { return better(cxp, cyp, a, o); };
+      if (solo) wave_best(best, right); else row_best(best, right);
       if (!done) {
         if (best.idx < 0) done = true;                                   // single (repeated) point
         else if (best.x == st.x && best.y == st.y) done = true;          // ring closed
@@ -433,7 +448,7 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
     }
     __syncthreads();
     // < 3 extreme points = fewer than 3 unique points or a collinear cluster: the reference drops it (:70-76)
-    for (int qq = 0; qq < 4 && g + qq < nc; ++qq) {
+    for (int qq = 0; qq < ng; ++qq) {
       const int nv = __shfl(nvert, qq * 16, 64);
       if (nv >= 3) {
         if (n_out >= n_obs_max || nv > v_max) ovf = 1;
@@ -445,6 +460,7 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
       }
     }
     __syncthreads();
+    g += ng;
   }
   if (lane == 0) { n_inferred[b] = n_out; overflow[b] = ovf; }
 }
