@@ -21,7 +21,7 @@ class LipmpcParamsC(C.Structure):
 
 
 EXPORTS = ("lipmpc_default_params", "lipmpc_create", "lipmpc_destroy", "lipmpc_num_rows",
-           "lipmpc_active_words", "lipmpc_plan_step_batch", "lipmpc_advance_batch", "lipmpc_rollout_batch", "lipmpc_lidar_sense_batch",
+           "lipmpc_active_words", "lipmpc_plan_step_batch", "lipmpc_advance_batch", "lipmpc_fleet_update_batch", "lipmpc_rollout_batch", "lipmpc_lidar_sense_batch",
            "lipmpc_strerror", "lipmpc_version")
 
 _lib = None
@@ -52,6 +52,8 @@ def load():
     lib.lipmpc_plan_step_batch.restype = i32
     lib.lipmpc_advance_batch.argtypes = [vp, i64] + [vp] * 6
     lib.lipmpc_advance_batch.restype = i32
+    lib.lipmpc_fleet_update_batch.argtypes = [vp, i64, C.c_int32, C.c_double] + [vp] * 17
+    lib.lipmpc_fleet_update_batch.restype = i32
     lib.lipmpc_rollout_batch.argtypes = [vp, i64, C.c_int32, C.c_int32, C.c_double] + [vp] * 13
     lib.lipmpc_rollout_batch.restype = i32
     lib.lipmpc_lidar_sense_batch.argtypes = ([i32, i64] + [C.c_int32] * 4 + [C.c_double, C.c_double] + [C.c_int32] * 3

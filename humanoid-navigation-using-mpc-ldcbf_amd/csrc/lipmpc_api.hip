@@ -24,6 +24,46 @@ __global__ void advance_kernel(long B, double ch, double sh_over_beta, double be
   foot[b] = (int8_t)(-foot[b]);
 }
 
+// one sample of a host-driven fleet loop (include/lipmpc.h: lipmpc_fleet_update_batch)
+__global__ void fleet_update_kernel(long B, int k_max, double stop_obj, double ch, double sh_over_beta, double beta_sh, int N,
+                                    double* __restrict__ state, int8_t* __restrict__ foot, int8_t* __restrict__ walking,
+                                    double* __restrict__ last_obj, int32_t* __restrict__ n_steps,
+                                    int32_t* __restrict__ last_status, int32_t* __restrict__ n_overflow,
+                                    const int32_t* __restrict__ sample, double* __restrict__ X_pred,
+                                    double* __restrict__ U_pred, const double* __restrict__ U,
+                                    const double* __restrict__ theta, const double* __restrict__ omega,
+                                    const double* __restrict__ obj, const int32_t* __restrict__ status,
+                                    const int32_t* __restrict__ overflow) {
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int k = *sample;
+  if (k >= k_max) return;
+  bool w = walking[b] != 0 && last_obj[b] >= stop_obj;
+  const int st = status[b];
+  if (w) last_status[b] = st;
+  w = w && (st == LIPMPC_STATUS_SOLVED || st == LIPMPC_STATUS_UNCERTIFIED);
+  double* x = state + b * 5;
+  const double ux = U[b * N * 2 + 0], uy = U[b * N * 2 + 1];
+  if (w) {
+    last_obj[b] = obj[b];
+    const double px = x[0], vx = x[1], py = x[2], vy = x[3];
+    x[0] = ch * px + sh_over_beta * vx + (1.0 - ch) * ux;
+    x[1] = beta_sh * px + ch * vx - beta_sh * ux;
+    x[2] = ch * py + sh_over_beta * vy + (1.0 - ch) * uy;
+    x[3] = beta_sh * py + ch * vy - beta_sh * uy;
+    x[4] = theta[b * (N + 1) + 1];
+    foot[b] = (int8_t)(-foot[b]);
+    n_steps[b] += 1;
+    if (overflow) n_overflow[b] += overflow[b];
+  }
+  walking[b] = w ? 1 : 0;
+  double* up = U_pred + (b * (long)k_max + k) * 3;
+  up[0] = ux; up[1] = uy; up[2] = omega[b * N];
+  double* xp = X_pred + (b * (long)(k_max + 1) + k + 1) * 5;
+  for (int i = 0; i < 5; ++i) xp[i] = x[i];
+}
+__global__ void fleet_next_sample_kernel(int32_t* sample) { *sample += 1; }
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -167,6 +207,24 @@ int lipmpc_advance_batch(lipmpc_handle* h, int64_t B, double* state, int8_t* fir
   if (hipSetDevice(h->device) != hipSuccess) return LIPMPC_E_HIP;
   hipLaunchKernelGGL(advance_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
                      (long)B, h->k.ch, h->k.sh_over_beta, h->k.beta_sh, state, first_foot, U, theta, status, h->k.N);
+  return hipGetLastError() == hipSuccess ? LIPMPC_OK : LIPMPC_E_HIP;
+}
+
+int lipmpc_fleet_update_batch(lipmpc_handle* h, int64_t B, int32_t k_max, double stop_obj, double* state,
+                              int8_t* first_foot, int8_t* walking, double* last_obj, int32_t* n_steps,
+                              int32_t* last_status, int32_t* n_overflow, int32_t* sample, double* X_pred, double* U_pred,
+                              const double* U, const double* theta, const double* omega, const double* obj,
+                              const int32_t* status, const int32_t* overflow, void* hip_stream) {
+  if (!h || B < 0 || k_max < 1) return LIPMPC_E_ARG;
+  if (B == 0) return LIPMPC_OK;
+  if (!state || !first_foot || !walking || !last_obj || !n_steps || !last_status || !sample || !X_pred || !U_pred || !U ||
+      !theta || !omega || !obj || !status || (overflow && !n_overflow))
+    return LIPMPC_E_ARG;
+  if (hipSetDevice(h->device) != hipSuccess) return LIPMPC_E_HIP;
+  hipLaunchKernelGGL(fleet_update_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, (long)B,
+                     k_max, stop_obj, h->k.ch, h->k.sh_over_beta, h->k.beta_sh, h->k.N, state, first_foot, walking, last_obj,
+                     n_steps, last_status, n_overflow, sample, X_pred, U_pred, U, theta, omega, obj, status, overflow);
+  hipLaunchKernelGGL(fleet_next_sample_kernel, dim3(1), dim3(1), 0, (hipStream_t)hip_stream, sample);
   return hipGetLastError() == hipSuccess ? LIPMPC_OK : LIPMPC_E_HIP;
 }
 

@@ -129,39 +129,27 @@ class UnknownEnvFleet:
         clusters did not fit the obstacle slots)."""
         dev, sv, sn = self.device, self.solver, self.sensor
         B = state0.shape[0]
-        state, foot = state0.clone(), first_foot.clone()
         X = torch.zeros((B, k_max + 1, 5), dtype=torch.float64, device=dev)
-        U = torch.zeros((B, k_max, 3), dtype=torch.float64, device=dev)
-        X[:, 0] = state
-        alive = torch.ones((B,), dtype=torch.bool, device=dev)
-        last_obj = torch.full((B,), float("inf"), dtype=torch.float64, device=dev)
-        n_steps = torch.zeros((B,), dtype=torch.int32, device=dev)
-        last_status = torch.zeros((B,), dtype=torch.int32, device=dev)
-        n_overflow = torch.zeros((B,), dtype=torch.int32, device=dev)
-        u_k = torch.zeros((B, 3), dtype=torch.float64, device=dev)
+        X[:, 0] = state0
+        fl = dict(state=state0.clone(), first_foot=first_foot.clone(),
+                  walking=torch.ones((B,), dtype=torch.int8, device=dev),
+                  last_obj=torch.full((B,), float("inf"), dtype=torch.float64, device=dev),
+                  n_steps=torch.zeros((B,), dtype=torch.int32, device=dev),
+                  last_status=torch.zeros((B,), dtype=torch.int32, device=dev),
+                  n_overflow=torch.zeros((B,), dtype=torch.int32, device=dev),
+                  sample=torch.zeros((1,), dtype=torch.int32, device=dev),
+                  X_pred=X, U_pred=torch.zeros((B, k_max, 3), dtype=torch.float64, device=dev))
         sen = sn.alloc_outputs(B)
         out = sv.alloc_outputs(B)
         nbuf = None if noise is None else torch.zeros((B, sn.resolution, 2), dtype=torch.float64, device=dev)
         gen = torch.Generator(device=dev).manual_seed(int(noise_seed)) if isinstance(noise, str) else None
-        nxt_state, nxt_foot = state.clone(), foot.clone()
 
         def sample():
-            # HumanoidMpc.py:392 stop rule, :387/:417 sense + solve, :419-429 failed solve ends the run, :432-447 advance
-            alive.logical_and_(last_obj >= stop_obj)
-            sn.sense(state, nbuf, out=sen)
-            sv.plan_step_batch(state, goal, foot, sen["obs_xy"], sen["obs_nv"], delta, out=out)
-            ok = (out["status"] == 0) | (out["status"] == 4)
-            last_status.copy_(torch.where(alive, out["status"], last_status))
-            alive.logical_and_(ok)
-            last_obj.copy_(torch.where(alive, out["obj"], last_obj))
-            nxt_state.copy_(state); nxt_foot.copy_(foot)
-            sv.advance(nxt_state, nxt_foot, out)
-            state.copy_(torch.where(alive[:, None], nxt_state, state))
-            foot.copy_(torch.where(alive, nxt_foot, foot))
-            u_k[:, :2] = out["U"][:, 0]
-            u_k[:, 2] = out["omega"][:, 0]
-            n_steps.add_(alive.to(torch.int32))
-            n_overflow.add_(sen["overflow"] * alive.to(torch.int32))
+            # HumanoidMpc.py:387/:417 sense + solve; :392 stop rule, :419-429 failed solve ends the run, :432-447 advance
+            # and the trajectory row: one bookkeeping launch (lipmpc_fleet_update_batch)
+            sn.sense(fl["state"], nbuf, out=sen)
+            sv.plan_step_batch(fl["state"], goal, fl["first_foot"], sen["obs_xy"], sen["obs_nv"], delta, out=out)
+            sv.fleet_update(fl, out, overflow=sen["overflow"], stop_obj=stop_obj)
 
         def fill_noise(k):
             if gen is not None:
@@ -172,27 +160,28 @@ class UnknownEnvFleet:
         graph = None
         if use_graph:
             fill_noise(0)
-            keep = [t.clone() for t in (state, foot, alive, last_obj, n_steps, last_status, n_overflow)]
+            names = ("state", "first_foot", "walking", "last_obj", "n_steps", "last_status", "n_overflow", "sample", "X_pred", "U_pred")
+            keep = {n: fl[n].clone() for n in names}
             side = torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
-                sample()                                     # warm-up outside capture (allocator, lazy init)
+                sample()                                     # warm-up outside capture (lazy initialisation)
             torch.cuda.current_stream(dev).wait_stream(side)
-            for t, c in zip((state, foot, alive, last_obj, n_steps, last_status, n_overflow), keep):
-                t.copy_(c)
+            for n in names:
+                fl[n].copy_(keep[n])
             if gen is not None:
                 gen.manual_seed(int(noise_seed))
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 sample()
-            for t, c in zip((state, foot, alive, last_obj, n_steps, last_status, n_overflow), keep):
-                t.copy_(c)
+            for n in names:
+                fl[n].copy_(keep[n])
         for k in range(k_max):
             fill_noise(k)
             if graph is not None:
                 graph.replay()
             else:
                 sample()
-            U[:, k] = u_k
-            X[:, k + 1] = state
-        return dict(X_pred=X, U_pred=U, n_steps=n_steps, last_status=last_status, overflow=n_overflow)
+        return dict(X_pred=fl["X_pred"], U_pred=fl["U_pred"], n_steps=fl["n_steps"], last_status=fl["last_status"],
+                    overflow=fl["n_overflow"])
+

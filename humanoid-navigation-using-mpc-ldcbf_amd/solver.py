@@ -153,6 +153,21 @@ class BatchedLipMpc:
         _lib.check(rc, "lipmpc_advance_batch")
 
 
+    def fleet_update(self, fleet, out, overflow=None, stop_obj=0.05):
+        """One sample of a host-driven fleet loop after ``plan_step_batch(..., out=out)`` on the same stream:
+        stop rule, stop on a failed solve, state advance, counters and the trajectory row, in one launch
+        (lipmpc_fleet_update_batch).  ``fleet`` = dict(state, first_foot, walking int8, last_obj, n_steps, last_status,
+        n_overflow, sample int32[1], X_pred [B,k_max+1,5], U_pred [B,k_max,3]); the device-side sample counter
+        advances by one per call."""
+        B, k_max = fleet["state"].shape[0], fleet["U_pred"].shape[1]
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.lib.lipmpc_fleet_update_batch(
+            self._h, B, int(k_max), float(stop_obj), _ptr(fleet["state"]), _ptr(fleet["first_foot"]), _ptr(fleet["walking"]),
+            _ptr(fleet["last_obj"]), _ptr(fleet["n_steps"]), _ptr(fleet["last_status"]), _ptr(fleet["n_overflow"]),
+            _ptr(fleet["sample"]), _ptr(fleet["X_pred"]), _ptr(fleet["U_pred"]), _ptr(out["U"]), _ptr(out["theta"]),
+            _ptr(out["omega"]), _ptr(out["obj"]), _ptr(out["status"]), _ptr(overflow), C.c_void_p(stream))
+        _lib.check(rc, "lipmpc_fleet_update_batch")
+
     def rollout(self, state0, goal, first_foot, obs_xy=None, obs_nv=None, delta=None, k_max=100, mpc_step=1,
                 stop_obj=0.05, bounds=None):
         """Closed loop on the device (HumanoidMpc.py:345-459) for B robots: returns dict(X_pred [B,k_max+1,5],

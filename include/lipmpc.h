@@ -120,6 +120,22 @@ int lipmpc_advance_batch(lipmpc_handle* h, int64_t B, double* state, int8_t* fir
                          const double* U, const double* theta, const int32_t* status,
                          void* hip_stream);
 
+/* One sample of a host-driven closed loop for a fleet (the bookkeeping of HumanoidMpc.py:392, 419-447 around a solve
+ * that was just enqueued on the same stream), per robot b:
+ *   walking[b] &= last_obj[b] >= stop_obj        (stop rule of this sample, from the previous objective, :392)
+ *   if walking: last_status[b] = status[b];  walking[b] &= status in {SOLVED, UNCERTIFIED}   (:419-429)
+ *   if still walking: last_obj = obj; state <- (A_l x + B_l U[b,0], theta[b,1]); first_foot <- -first_foot (:432-447);
+ *                     n_steps[b] += 1; n_overflow[b] += overflow[b] (if given)
+ *   U_pred[b, k, :] = (U[b,0,:], omega[b,0]);  X_pred[b, k+1, :] = state[b]   with k = *sample (read on the device)
+ * and one thread advances *sample by one, so that a captured graph can be replayed sample after sample.
+ * walking [B] int8 (1 = walking), sample [1] int32, X_pred [B,k_max+1,5], U_pred [B,k_max,3]; samples >= k_max are ignored. */
+int lipmpc_fleet_update_batch(lipmpc_handle* h, int64_t B, int32_t k_max, double stop_obj,
+                              double* state, int8_t* first_foot, int8_t* walking, double* last_obj,
+                              int32_t* n_steps, int32_t* last_status, int32_t* n_overflow, int32_t* sample,
+                              double* X_pred, double* U_pred,
+                              const double* U, const double* theta, const double* omega, const double* obj,
+                              const int32_t* status, const int32_t* overflow, void* hip_stream);
+
 /* Closed loop on the device: HumanoidMPC.run_simulation (HumanoidMpc.py:345-459) for B robots, one group of
  * lanes per robot for the whole run, no host round trip.  Per sample k < k_max: stop when the previous
  * step's objective < stop_obj (0.05 in the reference, :392); on MPC samples (k % mpc_step == 0,
