@@ -208,6 +208,27 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return fma(fma(-x, y, 1.0), y, y);
 }
 
+// acc + (value of `src` on lane J of the lane's DPP row) * mult in ONE instruction: v_fmac_f64 is the only FP64
+// arithmetic that takes a DPP operand on gfx950 (row_newbcast only), and the compiler never folds a
+// v_mov_b64_dpp into it, so it is written out.  Hazards the compiler would cover for its own DPP instructions are
+// covered by hand: a VGPR written by the previous VALU instruction needs 2 wait states before a DPP read
+// (s_nop 1); dpp_fence() before the first one of a sequence covers the 5 wait states after an EXEC write.
+#ifndef LIPMPC_DPP_NOP
+#define LIPMPC_DPP_NOP "s_nop 1\n\t"
+#endif
+template <int J> __device__ __forceinline__ double fmac_bcast(double acc, double src, double mult) {
+  asm(LIPMPC_DPP_NOP "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+      : "+v"(acc) : "v"(src), "v"(mult), "n"(J));
+  return acc;
+}
+template <int J> __device__ __forceinline__ double fmac_bcast_self(double acc, double mult) {
+  asm(LIPMPC_DPP_NOP "v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+      : "+v"(acc) : "v"(mult), "n"(J));
+  return acc;
+}
+__device__ __forceinline__ void dpp_fence() { asm volatile("s_nop 4"); }
+#include "lipmpc_fused_steps.inc"
+
 // x where c holds, otherwise x with its high word cleared (|value| < 2^-1042, i.e. nothing once it meets a normal
 // number in an FMA): ONE v_cndmask instead of the two a 64-bit select costs.  Use it on temporaries (broadcast
 // results, products), where the low word needs no copy.
@@ -309,6 +330,11 @@ __device__ __forceinline__ StepOut step_body(
   constexpr int NR = R_CBF + NOBS_R;   // local row slots held in registers
   constexpr int MAXOBS = 2 * NOBS_L;
   constexpr int MAXWORDS = 16;         // (9*16 + 17*50 + 63)/64 = 16
+#ifdef LIPMPC_NO_FUSED_DPP
+  constexpr bool FUSED = false;
+#else
+  constexpr bool FUSED = (G == 16);    // one-instruction substitution / elimination steps (fmac_bcast)
+#endif
 
   __shared__ double lds_obs[GPW][MAXOBS > 0 ? MAXOBS : 1][4];   // eta_x, eta_y, b = eta.c + delta, h0
   __shared__ double lds_P[GPW][NMAX][2][2];                     // P_b blocks of the velocity part of K
@@ -525,12 +551,24 @@ __device__ __forceinline__ StepOut step_body(
   auto bc16 = [](auto ic, double x) -> double {
     return __builtin_amdgcn_mov_dpp(x, 0x150 + decltype(ic)::value, 0xf, 0xf, false);
   };
+  // G = 16: the triangular factors in the form the fused substitution steps want them (solve):
+  //   Xl[j] = -Lt[l][j] / p_j on lanes l > j, 0 elsewhere;  Yu[j] = -Lt[j][l] / p_l ... = -ipiv_l S_l[j] on lanes l < j, 0 elsewhere
+  double Xl[FUSED ? NV : 1], Yu[FUSED ? NV : 1];
   auto factor = [&]() -> bool {
     bool ok = true;
     const int ln = lane;
+    if constexpr (FUSED) dpp_fence();
     static_for<0, NV>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      if constexpr (G == 16) {
+      if constexpr (FUSED) {
+        const double pj = gbcast<G, j>(Krow[j]);
+        ok = ok && (pj > 0.0);
+        const double ip = fast_rcp(pj);
+        const double nf = zero_unless(ln > j, Krow[j] * -ip);
+        if (ln == j) ipiv = ip;
+        Xl[j] = nf;
+        if constexpr (NV == 16) FactorStep<j>::run(Krow, nf);
+      } else if constexpr (G == 16) {
         const double pj = gbcast<G, j>(Krow[j]);
         ok = ok && (pj > 0.0);
         const double ip = fast_rcp(pj);
@@ -560,11 +598,32 @@ __device__ __forceinline__ StepOut step_body(
         });
       }
     });
+    if constexpr (FUSED) {
+      const double nip = -ipiv;
+      static_for<1, NV>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        Yu[j] = zero_unless(ln < j, Krow[j] * nip);
+      });
+    }
     return ok;
   };
   auto solve = [&](double b) -> double {
     const int ln = lane;
-    if constexpr (G == 16) {
+    if constexpr (FUSED) {
+      // forward: b_l += Xl_l[j] b_j (lanes l > j); lane j's b is final after step j-1.  backward on x = w - ipiv acc:
+      // x_l += Yu_l[j] x_j (lanes l < j), lane j final once the columns above it are done.  One instruction per step.
+      dpp_fence();
+      static_for<0, NV - 1>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        b = fmac_bcast_self<j>(b, Xl[j]);
+      });
+      double x = b * ipiv;
+      static_rfor<NV, 1>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        x = fmac_bcast_self<j>(x, Yu[j]);
+      });
+      return x;
+    } else if constexpr (G == 16) {
       // forward Lt w = b: w_j = b_j / p_j, b_l -= Lt[l][j] w_j (l > j); lane j's b is final after step j
       static_for<0, NV>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
