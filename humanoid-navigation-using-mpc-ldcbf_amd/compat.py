@@ -30,7 +30,7 @@ class HumanoidMPC:
     def __init__(self, goal, obstacles, N_horizon=3, N_mpc_timesteps=100, sampling_time=1e-3,
                  init_state: Union[np.ndarray, tuple] = np.array([0, 0, 0, 0, 0]),
                  start_with_right_foot: bool = True, verbosity: int = 1, *, exact: bool = False,
-                 device: int | None = None):
+                 interior_tol: float = 1e-6, device: int | None = None):
         # HumanoidMpc.py:66
         assert DELTA_T % sampling_time <= 1e-8, \
             "The sampling time must be lower than and divisible by the duration of the step."
@@ -56,6 +56,11 @@ class HumanoidMPC:
         self.precomputed_omega = None
         self.distance_from_obstacles = getattr(self, "distance_from_obstacles", 0.0)
         self._exact = exact
+        # Stop tolerance of the interior mode (exact=False).  1e-6 is where the reference's IPOPT (tol 1e-5,
+        # HumanoidMpc.py:99) ends its barrier schedule; with it the closed loops reproduce the reference's committed
+        # result figures (tests/golden/make_pdf_pins.py: run lengths, first steps).  Tighter values hug LDCBF
+        # boundaries more closely than IPOPT does and end runs in front of walls early.
+        self._interior_tol = interior_tol
         self._device = device
         self._solver = None
         self._rings = None
@@ -70,7 +75,8 @@ class HumanoidMPC:
 
     def _make_solver(self, n_obs, v_max):
         p = LipMpcParams(N=self.N_horizon, n_obs_max=n_obs, v_max=max(3, v_max),
-                         sampling_time=self.sampling_time, flags=0 if self._exact else FLAG_INTERIOR)
+                         sampling_time=self.sampling_time, flags=0 if self._exact else FLAG_INTERIOR,
+                         tol_interior=self._interior_tol)
         return BatchedLipMpc(p, self._device)
 
     def _plan(self, state5, s0):

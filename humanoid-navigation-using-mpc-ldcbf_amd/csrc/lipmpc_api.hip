@@ -39,7 +39,10 @@ __global__ void fleet_update_kernel(long B, int k_max, double stop_obj, double c
   const int k = *sample;
   if (k >= k_max) return;
   bool w = walking[b] != 0 && last_obj[b] >= stop_obj;
-  const int st = status[b];
+  // a scan whose clusters did not fit the obstacle slots is a failed sample: planning against a truncated
+  // obstacle list would let the robot walk through something it sensed
+  const int st = (overflow && overflow[b]) ? LIPMPC_STATUS_SENSOR_OVERFLOW : status[b];
+  if (w && overflow) n_overflow[b] += overflow[b];
   if (w) last_status[b] = st;
   w = w && (st == LIPMPC_STATUS_SOLVED || st == LIPMPC_STATUS_UNCERTIFIED);
   double* x = state + b * 5;
@@ -54,7 +57,6 @@ __global__ void fleet_update_kernel(long B, int k_max, double stop_obj, double c
     x[4] = theta[b * (N + 1) + 1];
     foot[b] = (int8_t)(-foot[b]);
     n_steps[b] += 1;
-    if (overflow) n_overflow[b] += overflow[b];
   }
   walking[b] = w ? 1 : 0;
   double* up = U_pred + (b * (long)k_max + k) * 3;

@@ -74,6 +74,7 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
   const double* exy = env_xy + b * env_stride * (long)n_env * v_env * 2;
   const int32_t* env = env_nv + b * env_stride * (long)n_env;
   int n_cand = 0;
+  int in_ovf = 0;                 // inputs beyond what this kernel holds: more than RMAX obstacles in range, rings longer than v_env
 
   // ---- 1. ray casting (compute_lidar_readings) ---------------------------------------------------
   // candidate obstacles: those whose bounding circle comes within the range (conservative: an obstacle that is
@@ -83,7 +84,8 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
     bool keep = false;
     double mx = 0.0, my = 0.0, rad = 0.0;
     if (j < n_env) {
-      const int nv = env[j];
+      int nv = env[j];
+      if (nv > v_env) { nv = v_env; in_ovf = 1; }
       const double* ring = exy + (long)j * v_env * 2;
       for (int e = 0; e < nv; ++e) { mx += ring[2 * e]; my += ring[2 * e + 1]; }
       if (nv > 0) {
@@ -100,6 +102,10 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
     }
     n_cand += __popcll(ball);
   }
+  // cand_ holds RMAX obstacles: the (RMAX+1)-th obstacle in range is dropped and the scan flagged (overflow), never
+  // read past the list
+  if (n_cand > RMAX) { n_cand = RMAX; in_ovf = 1; }
+  in_ovf = __any(in_ovf) ? 1 : 0;
   __syncthreads();
   for (int i = lane; i < RMAX; i += 64) {
     bool have = false;
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
           if (!__any(ddx * ddx + ddy * ddy <= cr * cr)) continue;
         }
         const int j = cand_[jc];
-        const int nv = env[j];
+        const int nv = min(env[j], v_env);
         const double* ring = exy + (long)j * v_env * 2;
         bool chave = false;
         double cx = 0.0, cy = 0.0, cd = lidar_range;
@@ -156,7 +162,12 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
   }
   __syncthreads();
 
-  if (dbg_stop == 1) return;
+#ifdef LIPMPC_LIDAR_PHASES
+#define LIDAR_PHASE_END(n) if (dbg_stop == (n)) return
+#else
+#define LIDAR_PHASE_END(n)
+#endif
+  LIDAR_PHASE_END(1);
   // ---- 2. DBSCAN ------------------------------------------------------------------------------------
   // Readings are first compacted in ray order (typically 110-200 of 360 rays return one): clustering and hulls then
   // sweep n points instead of RMAX slots.  Order is preserved, so "smallest core index" numbering, border-point
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
   __syncthreads();
   for (int i = lane; i < npad; i += 64) if (comp_[i] >= 0) comp_[i] = root_[i];
   __syncthreads();
-  if (dbg_stop == 2) return;
+  LIDAR_PHASE_END(2);
   // Connected components of the core points, label = smallest core index of the component.
   //  (1) forest: every core point points at its smallest core neighbour (lowest set bit of its neighbour row — no
   //      label reads), pointer jumping flattens the trees;
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
     if (!__any(changed)) break;
     flatten();
   }
-  if (dbg_stop == 4) return;
+  LIDAR_PHASE_END(4);
   // cluster root of every reading: own component for cores, smallest neighbouring core component for the rest
 #pragma unroll
   for (int k = 0; k < WORDS; ++k) {
@@ -330,7 +341,7 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
     root_[i] = (ci < 0) ? NO_ROOT : ((ci != NO_ROOT) ? ci : touch[k]);
   }
   __syncthreads();
-  if (dbg_stop == 5) return;
+  LIDAR_PHASE_END(5);
   // roots in ascending order = cluster labels 0, 1, ...
   int n_clusters = 0;
   for (int w = 0; w < NW; ++w) {
@@ -353,12 +364,12 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
     }
   }
 
-  if (dbg_stop == 3) return;
+  LIDAR_PHASE_END(3);
   // ---- 3. convex hull per cluster (create_convex_hull) ------------------------------------------------
   // Four clusters at a time, one per 16-lane DPP row: a row walks its own cluster's member list (compacted below) and
   // every "best next vertex" reduction is four in-row DPP steps — no LDS crossbar, no cross-row traffic.  Vertices
   // are staged in LDS (the neighbour rows are dead by now) and committed in cluster order for proper polygons only.
-  int n_out = 0, ovf = (n_clusters > 64) ? 1 : 0;
+  int n_out = 0, ovf = (n_clusters > 64 || in_ovf) ? 1 : 0;
   double* oxy = obs_xy + b * (long)n_obs_max * v_max * 2;
   int32_t* onv = obs_nv + b * (long)n_obs_max;
   for (int k = lane; k < n_obs_max; k += 64) onv[k] = 0;
@@ -478,8 +489,13 @@ extern "C" int lipmpc_lidar_sense_batch(int device, int64_t B, int32_t resolutio
   if (!state || !ray_table || !obs_xy || !obs_nv || !n_inferred || !overflow || (n_env > 0 && (!env_xy || !env_nv)))
     return LIPMPC_E_ARG;
   if (hipSetDevice(device) != hipSuccess) return LIPMPC_E_HIP;
-  // profiling aid (tools/lidar_phases.py): LIPMPC_LIDAR_STOP=1..5 ends the kernel after that phase; outputs are then undefined
+#ifdef LIPMPC_LIDAR_PHASES
+  // profiling build only (make CXXFLAGS+=-DLIPMPC_LIDAR_PHASES, tools/lidar_phases.py): LIPMPC_LIDAR_STOP=1..5 ends the
+  // kernel after that phase; outputs are then undefined.  The shipped library has no such knob.
   static const int dbg_stop = getenv("LIPMPC_LIDAR_STOP") ? atoi(getenv("LIPMPC_LIDAR_STOP")) : 0;
+#else
+  const int dbg_stop = 0;
+#endif
   hipLaunchKernelGGL(lidar_sense_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)hip_stream, (long)B, resolution, n_env,
                      v_env, (long)(env_shared ? 0 : 1), lidar_range, eps, min_samples, n_obs_max, v_max, state, env_xy, env_nv,
                      ray_table, noise, obs_xy, obs_nv, n_inferred, overflow, hits, labels, dbg_stop);

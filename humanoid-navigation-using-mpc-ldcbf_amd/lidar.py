@@ -56,16 +56,26 @@ class LidarSensor:
             out["labels"] = torch.empty((B, self.resolution), dtype=torch.int32, device=dev)
         return out
 
-    def sense(self, state, noise=None, with_debug=False, out=None):
+    def sense(self, state, noise=None, with_debug=False, out=None, env_xy=None, env_nv=None):
         """state [B,5] device tensor; noise [B,resolution,2] or None -> dict(obs_xy, obs_nv, n_inferred, overflow[, hits, labels]).
-        Vertex slots beyond obs_nv keep whatever an earlier call left there when ``out`` is reused."""
+        Vertex slots beyond obs_nv keep whatever an earlier call left there when ``out`` is reused.
+        ``env_xy`` [B,n_env,v_env,2] / ``env_nv`` [B,n_env] (device tensors): one true map PER ROBOT instead of the
+        sensor's shared map (env_shared = 0 of the C ABI)."""
         B, dev = state.shape[0], self.device
         if out is None:
             out = self.alloc_outputs(B, with_debug)
         stream = torch.cuda.current_stream(dev).cuda_stream
+        n_env, v_env, shared, exy, env = self.n_env, self.v_env, 1, self.env_xy, self.env_nv
+        if env_xy is not None:
+            if (env_xy.dim() != 4 or env_xy.shape[0] != B or env_xy.shape[3] != 2 or env_nv is None
+                    or tuple(env_nv.shape) != (B, env_xy.shape[1]) or env_xy.dtype != torch.float64
+                    or env_nv.dtype != torch.int32 or not env_xy.is_contiguous() or not env_nv.is_contiguous()
+                    or env_xy.device != dev or env_nv.device != dev):
+                raise ValueError("per-robot maps: env_xy [B,n_env,v_env,2] float64, env_nv [B,n_env] int32, contiguous, on the sensor's device")
+            n_env, v_env, shared, exy, env = int(env_xy.shape[1]), int(env_xy.shape[2]), 0, env_xy, env_nv
         rc = self.lib.lipmpc_lidar_sense_batch(
-            self.device_index, B, self.resolution, self.n_env, self.v_env, 1, self.lidar_range, DBSCAN_EPS,
-            DBSCAN_MIN_SAMPLES, self.n_obs_max, self.v_max, _ptr(state), _ptr(self.env_xy), _ptr(self.env_nv),
+            self.device_index, B, self.resolution, n_env, v_env, shared, self.lidar_range, DBSCAN_EPS,
+            DBSCAN_MIN_SAMPLES, self.n_obs_max, self.v_max, _ptr(state), _ptr(exy), _ptr(env),
             _ptr(self.table), _ptr(noise), _ptr(out["obs_xy"]), _ptr(out["obs_nv"]), _ptr(out["n_inferred"]),
             _ptr(out["overflow"]), _ptr(out.get("hits")), _ptr(out.get("labels")), C.c_void_p(stream))
         _lib.check(rc, "lipmpc_lidar_sense_batch")
@@ -85,7 +95,9 @@ class HumanoidMPCUnknownEnvironment(HumanoidMPC):
                          np.zeros(5) if init_state is None else init_state, start_with_right_foot, verbosity, **kw)
         # the reference scans `ch.points` (raw input order), HumanoidMPCUnknownEnvironment.py:46
         env = [np.asarray(o.points, float) if hasattr(o, "points") else np.asarray(o, float) for o in obstacles]
+        self._env = env
         self._sensor = LidarSensor(env, lidar_range, lidar_resolution, device=self._device)
+        self._big_sensor = None
         self._gen = None if noise_seed is None else torch.Generator(device=self._sensor.device).manual_seed(int(noise_seed))
         self.list_inferred_obstacles = []
 
@@ -97,6 +109,17 @@ class HumanoidMPCUnknownEnvironment(HumanoidMPC):
             noise = NOISE_STD * torch.randn((1, self.lidar_resolution, 2), dtype=torch.float64, device=dev, generator=self._gen)
         out = self._sensor.sense(st, noise)
         torch.cuda.synchronize(dev)
+        if int(out["overflow"][0]):
+            # more clusters / longer hulls than the default slots: scan again (same noise) into the largest layout the
+            # step solver takes; the reference constrains against every inferred obstacle (:55-64), so a scan that
+            # still does not fit is an error, not a truncated obstacle list
+            if self._big_sensor is None:
+                self._big_sensor = LidarSensor(self._env, self.lidar_range, self.lidar_resolution, n_obs_max=50, v_max=32,
+                                               device=self._device)
+            out = self._big_sensor.sense(st, noise)
+            torch.cuda.synchronize(dev)
+            if int(out["overflow"][0]):
+                raise RuntimeError("LiDAR scan inferred more obstacles / hull vertices than the solver holds (50 x 32)")
         n = int(out["n_inferred"][0])
         nv = out["obs_nv"][0].cpu().numpy()
         xy = out["obs_xy"][0].cpu().numpy()
@@ -114,19 +137,20 @@ class UnknownEnvFleet:
     0.05) and stop-on-failed-solve per robot."""
 
     def __init__(self, env_rings, N_horizon=3, lidar_range=3.0, resolution=360, n_obs_max=12, v_max=32,
-                 exact=False, device=None):
+                 exact=False, interior_tol=1e-6, device=None):
         from .solver import BatchedLipMpc, LipMpcParams, FLAG_INTERIOR
         self.sensor = LidarSensor(env_rings, lidar_range, resolution, n_obs_max, v_max, device)
         self.solver = BatchedLipMpc(LipMpcParams(N=N_horizon, n_obs_max=n_obs_max, v_max=v_max,
-                                                 flags=0 if exact else FLAG_INTERIOR), self.sensor.device_index)
+                                                 flags=0 if exact else FLAG_INTERIOR, tol_interior=interior_tol),
+                                    self.sensor.device_index)
         self.device = self.sensor.device
 
     def run(self, state0, goal, first_foot, k_max, noise="seeded", noise_seed=0, delta=None, stop_obj=0.05,
             use_graph=True):
         """state0 [B,5], goal [B,2], first_foot [B] int8.  noise: "seeded" (N(0, 0.01) per reading from a generator
         seeded with noise_seed), None (noiseless) or a tensor [k_max,B,resolution,2].  Returns dict(X_pred
-        [B,k_max+1,5], U_pred [B,k_max,3], n_steps [B] solved samples, last_status [B], overflow [B] samples whose
-        clusters did not fit the obstacle slots)."""
+        [B,k_max+1,5], U_pred [B,k_max,3], n_steps [B] solved samples, last_status [B] (STATUS_SENSOR_OVERFLOW = 5: the
+        robot was stopped because a scan's clusters did not fit the obstacle slots), overflow [B] number of such scans)."""
         dev, sv, sn = self.device, self.solver, self.sensor
         B = state0.shape[0]
         X = torch.zeros((B, k_max + 1, 5), dtype=torch.float64, device=dev)

@@ -37,6 +37,10 @@ extern "C" {
                                          the reference raises inside solve() here (HumanoidMpc.py:419-429) */
 #define LIPMPC_STATUS_DEGENERATE   3  /* x == c or zero-length edge: reference yields NaN (ObstaclesUtils.py:81,104) */
 #define LIPMPC_STATUS_UNCERTIFIED  4  /* interior-point tolerance met, active-set finish not certified */
+#define LIPMPC_STATUS_SENSOR_OVERFLOW 5 /* written by lipmpc_fleet_update_batch only (last_status): the sample's inferred
+                                         obstacles did not fit the slots (overflow[b] != 0), the robot is stopped rather
+                                         than planned against a truncated obstacle list -- the reference constrains
+                                         against every inferred obstacle, HumanoidMPCUnknownEnvironment.py:55-64 */
 
 /* flags */
 #define LIPMPC_FLAG_INTERIOR 1  /* skip the active-set finish: return the strictly interior
@@ -123,7 +127,7 @@ int lipmpc_advance_batch(lipmpc_handle* h, int64_t B, double* state, int8_t* fir
 /* One sample of a host-driven closed loop for a fleet (the bookkeeping of HumanoidMpc.py:392, 419-447 around a solve
  * that was just enqueued on the same stream), per robot b:
  *   walking[b] &= last_obj[b] >= stop_obj        (stop rule of this sample, from the previous objective, :392)
- *   if walking: last_status[b] = status[b];  walking[b] &= status in {SOLVED, UNCERTIFIED}   (:419-429)
+ *   if walking: last_status[b] = overflow[b] ? SENSOR_OVERFLOW : status[b];  walking[b] &= last_status in {SOLVED, UNCERTIFIED}   (:419-429)
  *   if still walking: last_obj = obj; state <- (A_l x + B_l U[b,0], theta[b,1]); first_foot <- -first_foot (:432-447);
  *                     n_steps[b] += 1; n_overflow[b] += overflow[b] (if given)
  *   U_pred[b, k, :] = (U[b,0,:], omega[b,0]);  X_pred[b, k+1, :] = state[b]   with k = *sample (read on the device)
@@ -168,7 +172,8 @@ int lipmpc_rollout_batch(lipmpc_handle* h, int64_t B, int32_t k_max, int32_t mpc
  *             global, unseeded generator (:162-172); here the caller supplies the (seeded) sample.
  * outputs
  *  obs_xy [B,n_obs_max,v_max,2], obs_nv [B,n_obs_max]: CCW rings of the inferred obstacles, cluster order
- *  n_inferred [B]; overflow [B] = 1 if clusters/vertices did not fit (n_obs_max, v_max)
+ *  n_inferred [B]; overflow [B] = 1 if clusters/vertices did not fit (n_obs_max, v_max), if more than 384 true
+ *  obstacles were within range of the robot, or if an env_nv entry exceeded v_env (the surplus is dropped, never read)
  *  hits [B,resolution,2] (NaN = no reading) or NULL; labels [B,resolution] (-2 no reading, -1 noise, k cluster) or NULL
  */
 int lipmpc_lidar_sense_batch(int device, int64_t B, int32_t resolution, int32_t n_env, int32_t v_env,

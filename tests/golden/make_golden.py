@@ -10,7 +10,7 @@ Outputs (committed, data only):
                        ObstaclesUtils.is_point_inside_polygon (inside)   [ObstaclesUtils.py:50-109]
   fields_cfg2.npz      generate_obstacles fields, seeds 0..255, the BASELINE config-2 call
                        (obstacles.py:198-206): rings padded to 5 vertices + counts
-  fields_cfg4.npz      same generator, 50 obstacles, box (0.5,15.5)^2, seeds 0..7
+  fields_cfg4.npz      same generator, 50 obstacles, box (0.5,15.5)^2, seeds 0..31
   scenario_circles.npz Scenario.CIRCLE_OBSTACLES rings (Scenario.py:202-210)
 """
 import os
@@ -88,7 +88,7 @@ def main():
         R.append(r); V.append(n)
     np.savez_compressed(os.path.join(HERE, "fields_cfg2.npz"), rings=np.array(R), nv=np.array(V))
     R, V = [], []
-    for seed in range(8):
+    for seed in range(32):
         f = field(seed, 50, 15.5, (16, 16))
         r, n = pad_rings(f, 5)
         rr = np.zeros((50, 5, 2)); nn = np.zeros(50, np.int32)

@@ -1,0 +1,271 @@
+"""GPU parity at the sizes BASELINE.json's configs name (-m gpu), through the C ABI:
+
+  config 1  single robot, CIRCLE_OBSTACLES, N = 5 (and the reference's own figures, N = 3, through the drop-in classes)
+  config 2  B = 4096,  N = 8,  10 obstacles: UNCERTIFIED answers against the fully finished oracle
+  config 3  B = 32768, N = 8,  10 obstacles: properties on every problem, C oracle on a 4096 sample, shard independence
+  config 4  B = 4096,  N = 16, 50 obstacles: every problem against the C oracle, active sets bit for bit
+
+Bars: footsteps / CoM 1e-5 (north_star; observed ~1e-8), theta / omega 1e-12, statuses and active-constraint indices
+bit-exact on the decisive subset (identification margin >= 0.5 and certificate margin >= 1e-6 on both sides; the
+excluded share is printed and bounded)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+import lipmpc  # noqa: E402
+import lipmpc_oracle as O  # noqa: E402
+from helpers import (IPOPT_LIKE_TOL, PDF_RUNS, check_pdf_bars, load_rings, oracle_pdf_run, pdf_compare,  # noqa: E402
+                     pdf_scenario)
+
+
+def _dev(a, dt):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device="cuda")
+
+
+def _synth():
+    from importlib import import_module
+    return import_module("humanoid-navigation-using-mpc-ldcbf_amd.synth")
+
+
+def _walked_batch(B, N, n_obs, hi, goal_xy, seed, max_steps, n_fields=None, delta_mix=False):
+    """bench.py's input recipe: generate_obstacles-distributed fields, states = live robots of an on-device closed-loop
+    warm-up of 0..max_steps steps.  n_fields < B: fields are reused by several robots (which stop at different steps)."""
+    synth = _synth()
+    nf = n_fields or B
+    xy, nv = synth.synthetic_fields(nf, n_obs, 0.5, hi, (0.0, 0.0), goal_xy, seed=seed)
+    if nf < B:
+        rep = -(-B // nf)
+        xy, nv = np.tile(xy, (rep, 1, 1, 1))[:B], np.tile(nv, (rep, 1))[:B]
+    obs_xy, obs_nv = _dev(xy, torch.float64), _dev(nv, torch.int32)
+    goal = torch.tensor([goal_xy], dtype=torch.float64, device="cuda").repeat(B, 1).contiguous()
+    walker = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5, flags=lipmpc.FLAG_INTERIOR))
+    delta = torch.zeros((B,), dtype=torch.float64, device="cuda")
+    if delta_mix:
+        st0 = torch.zeros((B, 5), dtype=torch.float64, device="cuda")
+        ft0 = torch.ones((B,), dtype=torch.int8, device="cuda")
+        ce = walker.plan_step_batch(st0, goal, ft0, obs_xy, obs_nv, None, with_c_eta=True)["c_eta"]
+        clear = torch.where(obs_nv > 0, torch.linalg.norm(ce[:, :, :2], dim=2), torch.full_like(ce[:, :, 0], 1e9)).min(dim=1).values
+        delta[B // 2:] = torch.where(clear[B // 2:] > 0.45, 0.3, 0.0)
+    state, foot = synth.walk_states(walker, obs_xy, obs_nv, goal, max_steps, seed=seed + 1, delta=delta)
+    return dict(state=state, foot=foot, goal=goal, obs_xy=obs_xy, obs_nv=obs_nv, delta=delta, xy=xy, nv=nv)
+
+
+def _oracle(P, b, idx=None, n_threads=16):
+    import c_oracle
+    h = lambda t: t.cpu().numpy() if idx is None else t.cpu().numpy()[idx]
+    xy = b["xy"] if idx is None else b["xy"][idx]
+    nv = b["nv"] if idx is None else b["nv"][idx]
+    return c_oracle.plan_step_batch(P, h(b["state"]), h(b["goal"]), h(b["foot"]), xy, nv, h(b["delta"]), n_threads=n_threads)
+
+
+def _compare_with_oracle(tag, P, g, ref, min_decisive):
+    """statuses, footsteps, active sets; returns the observed agreement figures (also printed for the record)."""
+    gs, rs = g["status"], ref["status"]
+    solved_g, solved_r = np.isin(gs, (0, 4)), np.isin(rs, (0, 4))
+    assert np.array_equal(solved_g, solved_r), (tag, np.bincount(gs, minlength=5), np.bincount(rs, minlength=5))
+    assert np.array_equal(gs[~solved_g], rs[~solved_r])                  # the same failure code where both fail
+    same = gs == rs
+    ok = (gs == 0) & (rs == 0)
+    du = float(np.max(np.abs(g["U"][ok] - ref["U"][ok])))
+    dx = float(np.max(np.abs(g["X"][ok] - ref["X"][ok])))
+    assert du < 1e-5 and dx < 1e-5, (tag, du, dx)
+    assert np.max(np.abs(g["theta"] - ref["theta"])) < 1e-12 and np.max(np.abs(g["omega"] - ref["omega"])) < 1e-12
+    dit = np.abs(g["iters"][solved_g] - ref["iters"][solved_g])
+    decisive = ok & (g["diag"][:, 2] >= 0.5) & (ref["diag"][:, 2] >= 0.5) & (g["diag"][:, 3] >= 1e-6) & (ref["diag"][:, 3] >= 1e-6)
+    act_g = lipmpc.unpack_active(g["active"], P.num_rows)
+    act_r = lipmpc.unpack_active(ref["active"], P.num_rows)
+    mism = int(np.sum(np.any(act_g[decisive] != act_r[decisive], axis=1)))
+    info = dict(n=len(gs), status_equal=float(same.mean()), certified_both=float(ok.mean()), uncertified_gpu=int((gs == 4).sum()),
+                uncertified_oracle=int((rs == 4).sum()), max_dU=du, max_dX=dx, iters_equal=float((dit == 0).mean()),
+                iters_max_diff=int(dit.max()), decisive=float(decisive.sum() / max(ok.sum(), 1)), active_mismatch=mism)
+    print(tag, info)
+    assert mism == 0, (tag, info)                                          # active-constraint indices bit-exact
+    assert decisive.sum() >= min_decisive * ok.sum(), (tag, info)
+    assert dit.max() <= 1, (tag, info)
+    return info, ok
+
+
+def _check_uncertified(tag, P, b, g, tol=1e-5):
+    """An UNCERTIFIED answer is the interior-point iterate handed out as usable: it must lie within 1e-5 of the certified
+    optimum, which the oracle reaches when its finish may run 64 rounds."""
+    idx = np.where(g["status"] == 4)[0]
+    if len(idx) == 0:
+        print(tag, "no UNCERTIFIED answers")
+        return 0
+    P64 = lipmpc.LipMpcParams(**{**P.__dict__, "finish_rounds": 64})
+    ref = _oracle(P64, b, idx)
+    cert = ref["status"] == 0
+    du = np.max(np.abs(g["U"][idx][cert] - ref["U"][cert]), axis=(1, 2)) if cert.any() else np.zeros(0)
+    print(tag, f"UNCERTIFIED {len(idx)}: certified by the 64-round oracle {int(cert.sum())}, max |dU| {du.max() if len(du) else 0:.2e}")
+    assert cert.mean() >= 0.9, (tag, np.bincount(ref["status"], minlength=5))
+    assert du.max() <= tol, (tag, du.max())
+    return len(idx)
+
+
+def _properties(N, g, ok, c_eta, delta):
+    """size-independent checks on every solved problem: LIP dynamics along the returned trajectory, LDCBF half-spaces"""
+    A_, B_ = O.lip_matrices(O.Params(N=N))
+    X, U = g["X"][ok], g["U"][ok]
+    for k in range(N):
+        assert np.max(np.abs(X[:, k + 1] - (X[:, k] @ A_.T + U[:, k] @ B_.T))) < 1e-9
+    ce = c_eta[ok]
+    p = X[:, 1:, :][:, :, [0, 2]]
+    hval = np.einsum("bkc,bjc->bkj", p, ce[:, :, 2:]) - np.sum(ce[:, :, 2:] * ce[:, :, :2], axis=2)[:, None, :] - delta[ok][:, None, None]
+    present = np.any(ce[:, :, 2:] != 0.0, axis=2)[:, None, :]
+    assert np.where(present, hval, 0.0).min() > -1e-8
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# config 1
+# ---------------------------------------------------------------------------------------------------------------
+def test_config1_circles_horizon5(golden_dir):
+    """BASELINE configs[0]: single robot, the three circle-like obstacles of Scenario.CIRCLE_OBSTACLES, horizon N = 5,
+    init (0,0,3,0,0) -> goal (6,-3) (simulation_1.py:85-102 with N_horizon 5): the drop-in class against the oracle's
+    closed loop, and every step of that loop solved exactly on the GPU against the oracle (active sets included)."""
+    obs = load_rings(os.path.join(golden_dir, "scenario_circles.npz"))
+    kw = dict(N_horizon=5, N_mpc_timesteps=300, sampling_time=0.4, init_state=(0, 0, 3, 0, 0))
+    mpc = lipmpc.HumanoidMPC(goal=(6, -3), obstacles=obs, verbosity=0, **kw)
+    X, U, _ = mpc.run_simulation(None, make_fast_plot=False, fill_animator=False)
+    Xo, Uo = O.run_closed_loop((6, -3), obs, exact=False, params=O.Params(tol_interior=IPOPT_LIKE_TOL), **kw)
+    assert X.shape[0] == 5 and U.shape[0] == 3 and X.shape[1] == U.shape[1] + 1
+    assert abs(X.shape[1] - Xo.shape[1]) <= 3 and X.shape[1] > 60
+    n = min(12, X.shape[1], Xo.shape[1])
+    assert np.max(np.abs(X[:, :n] - Xo[:, :n])) < 1e-6 and np.max(np.abs(U[:, : n - 1] - Uo[:, : n - 1])) < 1e-5
+    assert np.hypot(X[0, -1] - 6, X[2, -1] + 3) < 0.3
+    # every state of the oracle's loop as one exact step problem
+    from test_gpu_parity import compare, run_gpu
+    probs = [(Xo[:, k].copy(), (6.0, -3.0), 1 if k % 2 == 0 else -1, obs, 0.0) for k in range(Xo.shape[1] - 1)]
+    res = run_gpu(probs, 5, 3, 24)
+    s = compare(probs, res, 5)
+    print("config 1, N=5 circles:", len(probs), s)
+    assert s["worst_u"] < 1e-7 and s["it_diff"] <= 1 and s["n_act_cmp"] >= 0.85 * len(probs)
+
+
+@pytest.mark.parametrize("run", PDF_RUNS)
+def test_reference_figures_through_the_drop_in_classes(golden_dir, run):
+    """The reference's committed result figures (the only numeric outputs of its CasADi/IPOPT path) against the GPU
+    drop-in classes: HumanoidMPC / HumanoidMPCCustomLCBF for the single-goal runs, HumanoidMPCWithRRT with the
+    sub-goals recovered from rrt_res.pdf for the RRT* runs; same bars as the oracle's own test."""
+    sc = pdf_scenario(golden_dir, run)
+    kw = dict(obstacles=sc["rings"], N_horizon=sc["N"], N_mpc_timesteps=300, sampling_time=0.4, verbosity=0)
+    if sc["subgoals"] is not None:
+        mpc = lipmpc.HumanoidMPCWithRRT(goal=sc["goal"], init_state=sc["init"], sub_goals=sc["subgoals"], **kw)
+    elif sc["delta"] > 0:
+        mpc = lipmpc.HumanoidMPCCustomLCBF(goal=sc["goal"], init_state=sc["init"], distance_from_obstacles=sc["delta"], **kw)
+    else:
+        mpc = lipmpc.HumanoidMPC(goal=sc["goal"], init_state=sc["init"], **kw)
+    X, U, _ = mpc.run_simulation(None, make_fast_plot=False, fill_animator=False)
+    cmp = pdf_compare(golden_dir, run, X, U)
+    print(run, X.shape[1], cmp)
+    check_pdf_bars(run, X, cmp)
+    Xo, Uo = oracle_pdf_run(golden_dir, run)
+    n = min(10, X.shape[1], Xo.shape[1])
+    assert np.max(np.abs(X[:, :n] - Xo[:, :n])) < 1e-6            # and the oracle's loop, tightly, while they are in step
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# config 2: UNCERTIFIED answers
+# ---------------------------------------------------------------------------------------------------------------
+def test_config2_uncertified_answers_are_within_tolerance():
+    B, N, n_obs = 4096, 8, 10
+    b = _walked_batch(B, N, n_obs, 9.5, (10.0, 10.0), seed=1234, max_steps=30, delta_mix=True)
+    P = lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5)
+    sv = lipmpc.BatchedLipMpc(P)
+    out = sv.plan_step_batch(b["state"], b["goal"], b["foot"], b["obs_xy"], b["obs_nv"], b["delta"], with_diag=True)
+    torch.cuda.synchronize()
+    g = {k: v.cpu().numpy() for k, v in out.items()}
+    ref = _oracle(P, b)
+    _compare_with_oracle("config 2", P, g, ref, min_decisive=0.9)
+    _check_uncertified("config 2", P, b, g)
+    # a cap of one finish round turns a few per cent of the batch UNCERTIFIED: the same bound must hold for all of them
+    P1 = lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5, finish_rounds=1)
+    out1 = lipmpc.BatchedLipMpc(P1).plan_step_batch(b["state"], b["goal"], b["foot"], b["obs_xy"], b["obs_nv"], b["delta"], with_diag=True)
+    torch.cuda.synchronize()
+    g1 = {k: v.cpu().numpy() for k, v in out1.items()}
+    assert _check_uncertified("config 2, finish_rounds=1", P1, b, g1) > 100
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# config 3
+# ---------------------------------------------------------------------------------------------------------------
+def test_config3_batch_32768():
+    """BASELINE configs[2]: 32768 robots, N = 8, 10 obstacles.  One launch over the whole batch; properties on every
+    problem; the C oracle on a random 4096 sample; and the contiguous shards of 2 / 4 / 8 ranks (16384 / 8192 / 4096
+    per GPU, sharding.shard_bounds) give bit-identical rows to the one-launch result — the multi-GPU split has no
+    cross-problem coupling to get wrong."""
+    from importlib import import_module
+    sharding = import_module("humanoid-navigation-using-mpc-ldcbf_amd.sharding")
+    B, N, n_obs = 32768, 8, 10
+    b = _walked_batch(B, N, n_obs, 9.5, (10.0, 10.0), seed=77, max_steps=30, n_fields=8192, delta_mix=True)
+    P = lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5)
+    sv = lipmpc.BatchedLipMpc(P)
+    out = sv.plan_step_batch(b["state"], b["goal"], b["foot"], b["obs_xy"], b["obs_nv"], b["delta"], with_diag=True, with_c_eta=True)
+    out2 = sv.plan_step_batch(b["state"], b["goal"], b["foot"], b["obs_xy"], b["obs_nv"], b["delta"])
+    torch.cuda.synchronize()
+    g = {k: v.cpu().numpy() for k, v in out.items()}
+    assert np.array_equal(g["U"], out2["U"].cpu().numpy(), equal_nan=True)          # idempotent
+    solved = np.isin(g["status"], (0, 4))
+    print("config 3 statuses", np.bincount(g["status"], minlength=5), "iters mean", g["iters"][solved].mean(), "max", g["iters"].max())
+    assert solved.mean() > 0.99
+    _properties(N, g, solved, g["c_eta"], b["delta"].cpu().numpy())
+    idx = np.sort(np.random.default_rng(5).choice(B, 4096, replace=False))
+    ref = _oracle(P, b, idx)
+    gi = {k: v[idx] for k, v in g.items()}
+    _compare_with_oracle("config 3 (4096 sample)", P, gi, ref, min_decisive=0.9)
+    for world in (2, 4, 8):
+        for rank in (0, world - 1):
+            lo, hi = sharding.shard_bounds(B, rank, world)
+            assert hi - lo == B // world
+            o = sv.plan_step_batch(b["state"][lo:hi].contiguous(), b["goal"][lo:hi].contiguous(), b["foot"][lo:hi].contiguous(),
+                                   b["obs_xy"][lo:hi].contiguous(), b["obs_nv"][lo:hi].contiguous(), b["delta"][lo:hi].contiguous())
+            torch.cuda.synchronize()
+            assert np.array_equal(o["U"].cpu().numpy(), g["U"][lo:hi], equal_nan=True)
+            assert np.array_equal(o["status"].cpu().numpy(), g["status"][lo:hi])
+            assert np.array_equal(o["active"].cpu().numpy(), g["active"][lo:hi])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# config 4
+# ---------------------------------------------------------------------------------------------------------------
+def test_config4_full_size_against_c_oracle():
+    """BASELINE configs[3]: 4096 robots, N = 16, 50 obstacles (m = 944 rows, n = 32; 32 lanes per problem, LDCBF rows
+    streamed through LDS): every problem against the C oracle."""
+    B, N, n_obs = 4096, 16, 50
+    b = _walked_batch(B, N, n_obs, 15.5, (16.0, 16.0), seed=31, max_steps=20, n_fields=1024)
+    P = lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5)
+    sv = lipmpc.BatchedLipMpc(P)
+    out = sv.plan_step_batch(b["state"], b["goal"], b["foot"], b["obs_xy"], b["obs_nv"], b["delta"], with_diag=True, with_c_eta=True)
+    torch.cuda.synchronize()
+    g = {k: v.cpu().numpy() for k, v in out.items()}
+    ref = _oracle(P, b)
+    assert np.array_equal(g["c_eta"], ref["c_eta"])
+    info, ok = _compare_with_oracle("config 4", P, g, ref, min_decisive=0.75)
+    assert info["status_equal"] >= 0.97 and info["certified_both"] >= 0.9
+    _check_uncertified("config 4", P, b, g)
+    _properties(N, g, np.isin(g["status"], (0, 4)), g["c_eta"], b["delta"].cpu().numpy())
+
+
+def test_config4_reference_generated_fields(golden_dir):
+    """The same on obstacle fields produced by the reference's own generate_obstacles (fixture fields_cfg4.npz, 32 fields
+    of 50 polygons), states along the oracle's closed loops."""
+    from helpers import closed_loop_problems
+    import c_oracle
+    d = np.load(os.path.join(golden_dir, "fields_cfg4.npz"))
+    fields = [[d["rings"][f][j][: d["nv"][f][j]] for j in range(50)] for f in range(len(d["nv"]))]
+    probs = list(closed_loop_problems(16, 50, 32, 8, seed=1, fields=fields, goal=(16.0, 16.0)))
+    P = lipmpc.LipMpcParams(N=16, n_obs_max=50, v_max=5)
+    xy, nv = lipmpc.pack_rings([p[3] for p in probs], 50, 5)
+    st = np.array([p[0] for p in probs]); goal = np.array([p[1] for p in probs], float)
+    foot = np.array([p[2] for p in probs], np.int8); delta = np.array([p[4] for p in probs], float)
+    out = lipmpc.BatchedLipMpc(P).plan_step_batch(_dev(st, torch.float64), _dev(goal, torch.float64), _dev(foot, torch.int8),
+                                                  _dev(xy, torch.float64), _dev(nv, torch.int32), _dev(delta, torch.float64),
+                                                  with_diag=True, with_c_eta=True)
+    torch.cuda.synchronize()
+    g = {k: v.cpu().numpy() for k, v in out.items()}
+    ref = c_oracle.plan_step_batch(P, st, goal, foot, xy, nv, delta, n_threads=16)
+    assert np.array_equal(g["c_eta"], ref["c_eta"])
+    _compare_with_oracle("config 4 (reference fields)", P, g, ref, min_decisive=0.75)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import lipmpc_oracle as O
-from helpers import closed_loop_problems, load_rings
+from helpers import (PDF_RUNS, check_pdf_bars, closed_loop_problems, load_rings, oracle_pdf_run, pdf_compare)
 
 
 def test_geometry_matches_reference_golden(golden_dir):
@@ -106,6 +106,31 @@ def test_closed_loop_against_reference_pdf_trajectories(golden_dir):
                              init_state=(0, 0, 3, 0, 0), delta=0.0, exact=True)
     assert np.allclose(U[:2, 0], [-0.0335158, 3.0743530], atol=2e-7)
     assert np.allclose(U[:2, 1], [0.0419622, 2.7924542], atol=2e-7)
+
+
+@pytest.mark.parametrize("run", PDF_RUNS)
+def test_closed_loop_against_every_reproducible_reference_figure(golden_dir, run):
+    """Every closed loop of the reference whose inputs can be rebuilt, against the series in its committed result
+    figures (tests/golden/make_pdf_pins.py): the two circle runs, the wall run (300 steps on the spot), and the three
+    RRT* runs with their sub-goal lists recovered from rrt_res.pdf (3, 7 and 11 sub-goals, hand-off of
+    HumanoidMPCWithRRT.py:155-181).  These figures are the only numeric outputs of the CasADi/IPOPT path that exist;
+    the interior mode at IPOPT's final barrier value (helpers.IPOPT_LIKE_TOL) reproduces run lengths and first steps."""
+    X, U = oracle_pdf_run(golden_dir, run)
+    cmp = pdf_compare(golden_dir, run, X, U)
+    print(run, X.shape[1], cmp)
+    check_pdf_bars(run, X, cmp)
+
+
+def test_simulation1_figure_predates_the_committed_constraints(golden_dir):
+    """Assets/ReportResults/Simulation1 (simulation_1.py:33-50, BASE seed 7) is NOT a pin: its own velocity and heading
+    series violate the committed manoeuvrability row (HumanoidMpc.py:204-219, 238-243) at the very first step
+    (longitudinal velocity 0.50 against 0.8 - 3.6/pi * 0.49 = 0.238), so the figure was produced by an earlier
+    version of the constraints.  Recorded here so that nobody spends time matching it."""
+    P = np.load(os.path.join(golden_dir, "pdf_series.npz"))
+    vx, vy = P["Simulation1/ev1/s0"], P["Simulation1/ev1/s1"]
+    th, om = P["Simulation1/ev2/s0"], P["Simulation1/ev3/s0"]
+    lon = math.cos(th[1, 1]) * vx[1, 1] + math.sin(th[1, 1]) * vy[1, 1]
+    assert lon > 0.5 and 0.8 - 3.6 / math.pi * abs(om[0, 1]) < 0.24
 
 
 def test_status_codes():
