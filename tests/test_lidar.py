@@ -205,3 +205,97 @@ def test_gpu_unknown_environment_fleet_matches_class(golden_dir):
         assert r["n_steps"].min() >= 5 and r["overflow"].sum() == 0
     assert np.array_equal(res[False]["X_pred"], res[True]["X_pred"])
     assert np.array_equal(res[False]["n_steps"], res[True]["n_steps"])
+
+
+@pytest.mark.gpu
+def test_gpu_per_robot_maps_and_input_limits(golden_dir):
+    """env_shared = 0 (one true map per robot, include/lipmpc.h) gives each robot exactly what the shared-map call
+    gives it on its own map; more than 384 obstacles in range, or a ring longer than v_env, is flagged as overflow and
+    never read past the kernel's candidate list; bad arguments are refused before any launch."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    import lipmpc
+    d = np.load(os.path.join(golden_dir, "lidar_golden.npz"))
+    lr = float(d["lidar_range"][0])
+    cases = [i for i in range(len(d["pos"])) if float(d["lidar_range"][i]) == lr][:6]
+    B = len(cases)
+    assert B >= 3
+    maps, poss, noises = [], [], []
+    for i in cases:
+        pos, rings, rng = _case(d, i)
+        maps.append(rings); poss.append(pos); noises.append(d["noise"][i])
+    n_env = max(len(m) for m in maps); v_env = max(len(r) for m in maps for r in m)
+    exy = np.zeros((B, n_env, v_env, 2)); env = np.zeros((B, n_env), np.int32)
+    for i, m in enumerate(maps):
+        for j, r in enumerate(m):
+            exy[i, j, :len(r)] = r; env[i, j] = len(r)
+    st = np.zeros((B, 5)); st[:, 0] = [p[0] for p in poss]; st[:, 2] = [p[1] for p in poss]
+    sensor = lipmpc.LidarSensor(maps[0], lidar_range=lr, n_obs_max=12, v_max=40)
+    d_st, d_noise = torch.as_tensor(st, device="cuda"), torch.as_tensor(np.array(noises), device="cuda")
+    out = sensor.sense(d_st, d_noise, with_debug=True, env_xy=torch.as_tensor(exy, device="cuda"), env_nv=torch.as_tensor(env, device="cuda"))
+    torch.cuda.synchronize()
+    for i in range(B):
+        own = lipmpc.LidarSensor(maps[i], lidar_range=lr, n_obs_max=12, v_max=40)
+        o = own.sense(d_st[i:i + 1].contiguous(), d_noise[i:i + 1].contiguous(), with_debug=True)
+        torch.cuda.synchronize()
+        for k in ("n_inferred", "overflow", "obs_nv", "labels"):
+            assert torch.equal(out[k][i], o[k][0]), (i, k)
+        n = int(o["n_inferred"][0])
+        for j in range(n):
+            nv = int(o["obs_nv"][0, j])
+            assert torch.equal(out["obs_xy"][i, j, :nv], o["obs_xy"][0, j, :nv])
+        assert n == int((d["inf_nv"][cases[i]] > 0).sum())        # and it is the reference's answer for that map
+    with pytest.raises(ValueError):
+        sensor.sense(d_st, d_noise, env_xy=torch.as_tensor(exy[:2], device="cuda"), env_nv=torch.as_tensor(env[:2], device="cuda"))
+    # 500 small squares around the robot, all in range: the candidate list holds 384 -> overflow flag, no fault
+    rng = np.random.default_rng(1)
+    ang = rng.uniform(0, 2 * np.pi, 500); rad = rng.uniform(0.5, 1.4, 500)
+    sq = np.array([[-0.01, -0.01], [0.01, -0.01], [0.01, 0.01], [-0.01, 0.01]])
+    many = [np.array([rad[k] * np.cos(ang[k]), rad[k] * np.sin(ang[k])]) + sq for k in range(500)]
+    crowded = lipmpc.LidarSensor(many, lidar_range=1.5, n_obs_max=12, v_max=32)
+    o = crowded.sense(torch.zeros((3, 5), dtype=torch.float64, device="cuda"), None)
+    torch.cuda.synchronize()
+    assert o["overflow"].cpu().tolist() == [1, 1, 1]
+    # the same map with 300 obstacles fits the list (whatever the clustering says about slots)
+    fits = lipmpc.LidarSensor(many[:300], lidar_range=1.5, n_obs_max=50, v_max=32)
+    o = fits.sense(torch.zeros((1, 5), dtype=torch.float64, device="cuda"), None, with_debug=True)
+    torch.cuda.synchronize()
+    assert int((~torch.isnan(o["hits"][0, :, 0])).sum()) > 100
+    # a ring count beyond v_env is clamped and flagged
+    bad_nv = torch.as_tensor(np.full((1, 1), 9, np.int32), device="cuda")
+    one = lipmpc.LidarSensor([sq + 1.0], lidar_range=3.0)
+    o = one.sense(torch.zeros((1, 5), dtype=torch.float64, device="cuda"), None,
+                  env_xy=torch.as_tensor((sq + 1.0)[None, None], device="cuda").contiguous(), env_nv=bad_nv)
+    torch.cuda.synchronize()
+    assert int(o["overflow"][0]) == 1
+    # argument errors never reach the device
+    lib = lipmpc._lib.load()
+    z = C.c_void_p(0)
+    assert lib.lipmpc_lidar_sense_batch(0, 1, 400, 0, 1, 1, C.c_double(1.5), C.c_double(0.3), 3, 12, 32, z, z, z, z, z, z, z, z, z, z, z, z) == -1
+    assert lib.lipmpc_lidar_sense_batch(0, 1, 360, 0, 1, 1, C.c_double(1.5), C.c_double(0.3), 3, 12, 99, z, z, z, z, z, z, z, z, z, z, z, z) == -1
+
+
+@pytest.mark.gpu
+def test_gpu_more_clusters_than_slots(golden_dir):
+    """A ring of 14 separate posts around the robot = 14 clusters for 12 default slots: the drop-in class scans again into
+    the large layout and plans against all 14 (the reference constrains against every inferred obstacle,
+    HumanoidMPCUnknownEnvironment.py:55-64); the fleet loop stops such a robot with STATUS_SENSOR_OVERFLOW instead of
+    walking it through obstacles it sensed."""
+    torch = pytest.importorskip("torch")
+    import lipmpc
+    posts = []
+    for k in range(14):                       # 0.60 m between centres, 0.48 m between surfaces: 14 DBSCAN clusters (eps 0.3)
+        a = 2 * np.pi * k / 14
+        c = np.array([1.35 * np.cos(a), 1.35 * np.sin(a)])
+        posts.append(c + 0.06 * np.array([[np.cos(t), np.sin(t)] for t in np.linspace(0, 2 * np.pi, 9)[:-1]]))
+    mpc = lipmpc.HumanoidMPCUnknownEnvironment(goal=(5, 0.3), obstacles=posts, N_horizon=3, N_mpc_timesteps=3, sampling_time=0.4,
+                                               init_state=(0, 0, 0, 0, 0), verbosity=0, lidar_range=1.5, noise_seed=2)
+    X, U, _ = mpc.run_simulation(None, make_fast_plot=False, fill_animator=False)
+    assert len(mpc.list_inferred_obstacles[0]) == 14 and X.shape[1] >= 2
+    fleet = lipmpc.UnknownEnvFleet(posts, N_horizon=3, lidar_range=1.5, n_obs_max=12)
+    st0 = torch.zeros((2, 5), dtype=torch.float64, device="cuda"); st0[1, 0] = 4.0        # robot 1 sees only a few posts
+    goal = torch.tensor([[5.0, 0.3]] * 2, dtype=torch.float64, device="cuda")
+    r = fleet.run(st0, goal, torch.ones((2,), dtype=torch.int8, device="cuda"), 4, noise_seed=2)
+    torch.cuda.synchronize()
+    assert int(r["n_steps"][0]) == 0 and int(r["last_status"][0]) == lipmpc.STATUS_SENSOR_OVERFLOW and int(r["overflow"][0]) == 1
+    assert int(r["n_steps"][1]) == 4 and int(r["overflow"][1]) == 0
