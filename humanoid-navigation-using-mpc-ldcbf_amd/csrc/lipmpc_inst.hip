@@ -9,9 +9,9 @@ void launch_plan_step(const KArgs& k, long B, const double* state, const double*
                       const double* delta, const double* obs_xy, const int32_t* obs_nv, double* U, double* X,
                       double* theta, double* omega, double* obj, int32_t* status, int32_t* iters,
                       unsigned long long* active, double* c_eta, double* diag, const double* bounds, hipStream_t stream) {
-  constexpr int GPW = 64 / G;
+  constexpr int GPW = WAVE / G;
   const unsigned blocks = (unsigned)((B + GPW - 1) / GPW);
-  hipLaunchKernelGGL((plan_step_kernel<G, NOBS_L>), dim3(blocks), dim3(64), 0, stream, k, B, state, goal, first_foot,
+  hipLaunchKernelGGL((plan_step_kernel<G, NOBS_L>), dim3(blocks), dim3(WAVE), 0, stream, k, B, state, goal, first_foot,
                      delta, obs_xy, obs_nv, U, X, theta, omega, obj, status, iters, active, c_eta, diag, bounds);
 }
 
@@ -25,9 +25,9 @@ void launch_rollout(const KArgs& k, long B, int k_max, int mpc_step, double stop
                     const double* goal, const int8_t* first_foot, const double* delta, const double* obs_xy,
                     const int32_t* obs_nv, double* X_pred, double* U_pred, int32_t* n_steps, int32_t* last_status,
                     int32_t* total_iters, const double* bounds, hipStream_t stream) {
-  constexpr int GPW = 64 / G;
+  constexpr int GPW = WAVE / G;
   const unsigned blocks = (unsigned)((B + GPW - 1) / GPW);
-  hipLaunchKernelGGL((rollout_kernel<G, NOBS_L>), dim3(blocks), dim3(64), 0, stream, k, B, k_max, mpc_step, stop_obj,
+  hipLaunchKernelGGL((rollout_kernel<G, NOBS_L>), dim3(blocks), dim3(WAVE), 0, stream, k, B, k_max, mpc_step, stop_obj,
                      state0, goal, first_foot, delta, obs_xy, obs_nv, X_pred, U_pred, n_steps, last_status, total_iters, bounds);
 }
 

@@ -84,6 +84,15 @@ template <int I, int E, class F> __device__ __forceinline__ void static_rfor(F&&
   }
 }
 
+// The value of x, opaque to the optimiser: a lane-position predicate built from it (lane > j, lane & 16, ...) is
+// recomputed where it is used (one v_cmp) instead of being hoisted out of every loop as one more 64-bit lane mask
+// that lives in an SGPR pair for the whole kernel -- there are dozens of them, and they were most of the SGPR spills.
+__device__ __forceinline__ int fresh(int x) {
+#ifndef LIPMPC_NO_FRESH
+  asm volatile("" : "+v"(x));
+#endif
+  return x;
+}
 template <int CTRL, int BANK = 0xf, class T> __device__ __forceinline__ T dpp0(T x) {     // invalid source -> 0
   return __builtin_amdgcn_mov_dpp(x, CTRL, 0xf, BANK, true);        // no 'old' operand: no zero-init move
 }
@@ -118,7 +127,7 @@ template <class T> __device__ __forceinline__ void rowpair(T v, T& even_rep, T& 
 template <class T> __device__ __forceinline__ T rowswap(T v) {
   T e, o;
   rowpair(v, e, o);
-  const T r = (threadIdx.x & 16) ? e : o;
+  const T r = (fresh(threadIdx.x) & 16) ? e : o;
   return r;
 }
 template <int G, int M, class T> __device__ __forceinline__ T gxor(T x) {
@@ -136,7 +145,8 @@ template <int G, int J> __device__ __forceinline__ double gbcast(double x) {
   }
 }
 // value of the lane D below / above (0 outside the group)
-template <int G, int D> __device__ __forceinline__ double gup(double x, int lane) {
+template <int G, int D> __device__ __forceinline__ double gup(double x, int lane_) {
+  const int lane = (G == 16) ? lane_ : fresh(lane_);
   if constexpr (G == 16) return dpp0<0x110 + D>(x);
   else if constexpr (D == 16) { const double w = rowswap(x); return (lane & 16) ? w : 0.0; }
   else {
@@ -145,7 +155,8 @@ template <int G, int D> __device__ __forceinline__ double gup(double x, int lane
     return ((lane & 15) >= D) ? t : ((lane & 16) ? w : 0.0);
   }
 }
-template <int G, int D> __device__ __forceinline__ double gdown(double x, int lane) {
+template <int G, int D> __device__ __forceinline__ double gdown(double x, int lane_) {
+  const int lane = (G == 16) ? lane_ : fresh(lane_);
   if constexpr (G == 16) return dpp0<0x100 + D>(x);
   else if constexpr (D == 16) { const double w = rowswap(x); return (lane & 16) ? 0.0 : w; }
   else {
@@ -237,16 +248,40 @@ __device__ __forceinline__ double zero_unless(bool c, double x) {
   const unsigned hi = c ? (unsigned)(u >> 32) : 0u;
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned)u);
 }
+// Per-lane flags of a lane's row slots as bits of ONE register.  As `bool x[NR]` every flag is a 64-bit lane mask in
+// an SGPR pair that lives across the whole kernel: with the masks of the divergent regions that made several hundred
+// SGPR spills (v_writelane / v_readlane) per kernel.
+// A workgroup of these kernels is exactly ONE wavefront (WAVE = 64 threads: __launch_bounds__(WAVE), the launchers
+// pass dim3(WAVE), and the kernels trap on any other block size), so "barrier" means only: this wave's LDS writes are
+// visible to its own later LDS reads.  A wave's LDS operations execute in order; what is left to do is keep the
+// compiler from moving accesses across the point -- a workgroup-scope fence, no s_barrier.  Unlike __syncthreads()
+// this is well defined inside the divergent regions it is used in (groups of a wave leave the solver loops
+// independently).
+constexpr int WAVE = 64;
+__device__ __forceinline__ void wave_sync() {
+#ifdef LIPMPC_SYNCTHREADS
+  __syncthreads();
+#else
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+#endif
+}
+struct RowFlags {
+  unsigned m = 0u;
+  __device__ __forceinline__ bool operator[](int i) const { return (m >> i) & 1u; }
+  __device__ __forceinline__ void set(int i, bool v) { m = v ? (m | (1u << i)) : (m & ~(1u << i)); }
+};
 // ------------------------------------------------------------------------------------------
 // geometry: closest point on a convex ring, unit normal, inside flip (ObstaclesUtils.py:50-109)
 // contraction off so that comparisons see the same roundings as the CPU oracle
 // ------------------------------------------------------------------------------------------
-__device__ __noinline__ void closest_point_normal(const double* __restrict__ ring, int nv, double px, double py,
-                                                  double& cx, double& cy, double& ex, double& ey, bool& degenerate) {
+struct ClosestPoint { double cx, cy, ex, ey; int degenerate; };      // returned in registers: no stack traffic for the call
+__device__ __noinline__ ClosestPoint closest_point_normal(const double* __restrict__ ring, int nv, double px, double py) {
 #pragma clang fp contract(off)
   double best = INFINITY;
-  cx = NAN; cy = NAN;
-  degenerate = false;
+  ClosestPoint r;
+  r.cx = NAN; r.cy = NAN; r.ex = 0.0; r.ey = 0.0;
+  r.degenerate = 0;
   bool inside = false;
   double x0v = ring[2 * (nv - 1)], y0v = ring[2 * (nv - 1) + 1];
   bool f0 = y0v >= py;
@@ -258,14 +293,14 @@ __device__ __noinline__ void closest_point_normal(const double* __restrict__ rin
     double nrm = sqrt(dx * dx + dy * dy);
     double den = nrm * nrm;                      // sqrt-then-square, ObstaclesUtils.py:81
     if (den == 0.0) {
-      degenerate = true;
+      r.degenerate = 1;
     } else {
       double t = ((px - ax) * dx + (py - ay) * dy) / den;
       t = fmax(0.0, fmin(1.0, t));
       double qx = ax + t * dx, qy = ay + t * dy;
       double ux = qx - px, uy = qy - py;
       double d = sqrt(ux * ux + uy * uy);
-      if (d < best) { best = d; cx = qx; cy = qy; }
+      if (d < best) { best = d; r.cx = qx; r.cy = qy; }
     }
     // crossing test of edge (ring[i-1] -> ring[i]) with the +X ray (matplotlib Path.contains_point)
     bool f1 = ay >= py;
@@ -275,12 +310,13 @@ __device__ __noinline__ void closest_point_normal(const double* __restrict__ rin
     }
     x0v = ax; y0v = ay; f0 = f1;
   }
-  double nx = px - cx, ny = py - cy;
+  double nx = px - r.cx, ny = py - r.cy;
   double nn = sqrt(nx * nx + ny * ny);
-  if (!(nn > 0.0)) { degenerate = true; ex = 0.0; ey = 0.0; return; }
+  if (!(nn > 0.0)) { r.degenerate = 1; return r; }
   nx = nx / nn; ny = ny / nn;
   if (inside) { nx = -nx; ny = -ny; }
-  ex = nx; ey = ny;
+  r.ex = nx; r.ey = ny;
+  return r;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -385,7 +421,7 @@ __device__ __forceinline__ StepOut step_body(
 
   // ---- obstacles: c_j, eta_j at the current CoM (HumanoidMpc.py:296-319) ----------------------
   if (lane == 0) lds_flag[grp] = 0;
-  __syncthreads();
+  wave_sync();
   if (MAXOBS > 0) {
     for (int j = lane; j < MAXOBS; j += G) {
       if (j >= P.n_obs) {      // unused slot: absent (h0 = +inf), harmless values
@@ -396,8 +432,9 @@ __device__ __forceinline__ StepOut step_body(
       const int nv = obs_nv[oidx];
       double cx = 0, cy = 0, ex = 0, ey = 0, bb = 0, h0 = INFINITY;
       if (nv > 0) {
-        bool degen;
-        closest_point_normal(obs_xy + oidx * P.nvert_max * 2, nv, p0x, p0y, cx, cy, ex, ey, degen);
+        const ClosestPoint cp = closest_point_normal(obs_xy + oidx * P.nvert_max * 2, nv, p0x, p0y);
+        cx = cp.cx; cy = cp.cy; ex = cp.ex; ey = cp.ey;
+        const bool degen = cp.degenerate != 0;
         const double ec = ex * cx + ey * cy;
         bb = ec + delta;
         h0 = (ex * p0x + ey * p0y) - ec - delta;
@@ -411,17 +448,17 @@ __device__ __forceinline__ StepOut step_body(
       }
     }
   }
-  __syncthreads();
+  wave_sync();
   const int front_flag = lds_flag[grp];
 
   // per-lane LDCBF rows: obstacle j = 2t + c
   double oex[NOBS_R > 0 ? NOBS_R : 1], oey[NOBS_R > 0 ? NOBS_R : 1], ob[NOBS_R > 0 ? NOBS_R : 1];
-  bool pres[NR];
+  RowFlags pres;
 #pragma unroll
   for (int t = 0; t < NOBS_R; ++t) {
     const int j = 2 * t + c;
     oex[t] = lds_obs[grp][j][0]; oey[t] = lds_obs[grp][j][1]; ob[t] = lds_obs[grp][j][2];
-    pres[R_CBF + t] = var_on && (lds_obs[grp][j][3] != INFINITY);
+    pres.set(R_CBF + t, var_on && (lds_obs[grp][j][3] != INFINITY));
   }
   // streamed rows: presence bits, accessors
   unsigned pbits = 0u;
@@ -433,8 +470,8 @@ __device__ __forceinline__ StepOut step_body(
     ex = o[0]; ey = o[1]; b = o[2];
   };
   auto s_pm = [&](int t) -> double { return ((pbits >> t) & 1u) ? 1.0 : 0.0; };
-  pres[R_RU] = pres[R_RL] = pres[R_VU] = pres[R_VL] = var_on;
-  pres[R_M] = var_on && (c == 0);
+  pres.set(R_RU, var_on); pres.set(R_RL, var_on); pres.set(R_VU, var_on); pres.set(R_VL, var_on);
+  pres.set(R_M, var_on && (c == 0));
 
   // bounds of the non-LDCBF rows
   const double hi_r = P.l_max[c], lo_r = P.l_min[c];
@@ -523,7 +560,7 @@ __device__ __forceinline__ StepOut step_body(
     const double Fn0 = gdown<G, 2>(Fc0, lane), Fn1 = gdown<G, 2>(Fc1, lane);
     const double Dg0 = (c ? 0.0 : 2.0) - k2 * Ec0 + Fc0 + Fn0 + Cc0;
     const double Dg1 = (c ? 2.0 : 0.0) - k2 * Ec1 + Fc1 + Fn1 + Cc1;
-    __syncthreads();
+    wave_sync();
     // block b of the row: (-1)^(a+b) P_max(a,b) + [b==a] Dg - [b==a-1] F_a - [b==a+1] F_{a+1}; the three
     // indicator terms are FMAs against 0/1 masks (eqm), not selects.  Lanes/stages beyond N fall
     // out as rows of 2I because all their weights are zero.
@@ -539,7 +576,7 @@ __device__ __forceinline__ StepOut step_body(
       Krow[2 * b] = k0;
       Krow[2 * b + 1] = k1;
     }
-    __syncthreads();
+    wave_sync();
   };
   // Square-root-free right-looking factorisation K = Lt D^-1 Lt^T in full symmetric storage, one
   // row per lane, nothing rescaled: after step j lane j keeps row j of the Schur complement
@@ -556,7 +593,7 @@ __device__ __forceinline__ StepOut step_body(
   double Xl[FUSED ? NV : 1], Yu[FUSED ? NV : 1];
   auto factor = [&]() -> bool {
     bool ok = true;
-    const int ln = lane;
+    const int ln = fresh(lane);
     if constexpr (FUSED) dpp_fence();
     static_for<0, NV>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
@@ -602,13 +639,13 @@ __device__ __forceinline__ StepOut step_body(
       const double nip = -ipiv;
       static_for<1, NV>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        Yu[j] = zero_unless(ln < j, Krow[j] * nip);
+        Yu[j] = zero_unless(fresh(lane) < j, Krow[j] * nip);
       });
     }
     return ok;
   };
   auto solve = [&](double b) -> double {
-    const int ln = lane;
+    const int ln = fresh(lane);
     if constexpr (FUSED) {
       // forward: b_l += Xl_l[j] b_j (lanes l > j); lane j's b is final after step j-1.  backward on x = w - ipiv acc:
       // x_l += Yu_l[j] x_j (lanes l < j), lane j final once the columns above it are done.  One instruction per step.
@@ -955,12 +992,12 @@ __device__ __forceinline__ StepOut step_body(
   // (the logarithms cost ~2 us per wave: only when the caller asked for diag)
   double marg_l = INFINITY;
   const bool want_diag = diag != nullptr;
-  bool act[NR];
+  RowFlags act;
   unsigned abits = 0u;
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
     if (want_diag && pres[i]) marg_l = fmin(marg_l, fabs(log(z[i] / (FIN_IDENT * s[i]))));
-    act[i] = pres[i] && (z[i] > FIN_IDENT * s[i]);
+    act.set(i, pres[i] && (z[i] > FIN_IDENT * s[i]));
   }
   if constexpr (STREAM) {
 #pragma unroll STREAM_UNROLL
@@ -1094,7 +1131,7 @@ __device__ __forceinline__ StepOut step_body(
       if (!fin_done) {
         if (ymin < -FIN_EPS) {
 #pragma unroll
-          for (int i = 0; i < NR; ++i) if (act[i] && ci_of(i) == yi) { act[i] = false; y[i] = 0.0; }
+          for (int i = 0; i < NR; ++i) if (act[i] && ci_of(i) == yi) { act.set(i, false); y[i] = 0.0; }
           if constexpr (STREAM) {
 #pragma unroll STREAM_UNROLL
             for (int t = 0; t < NOBS_S; ++t)
@@ -1102,7 +1139,7 @@ __device__ __forceinline__ StepOut step_body(
           }
         } else if (smin < -FIN_EPS) {
 #pragma unroll
-          for (int i = 0; i < NR; ++i) if (pres[i] && !act[i] && ci_of(i) == si) act[i] = true;
+          for (int i = 0; i < NR; ++i) if (pres[i] && !act[i] && ci_of(i) == si) act.set(i, true);
           if constexpr (STREAM) {
 #pragma unroll STREAM_UNROLL
             for (int t = 0; t < NOBS_S; ++t)
@@ -1123,7 +1160,7 @@ __device__ __forceinline__ StepOut step_body(
       } else {
         status = LIPMPC_STATUS_UNCERTIFIED;
 #pragma unroll
-        for (int i = 0; i < NR; ++i) act[i] = pres[i] && (z[i] > FIN_IDENT * s[i]);
+        for (int i = 0; i < NR; ++i) act.set(i, pres[i] && (z[i] > FIN_IDENT * s[i]));
         abits = fbits;
       }
     }
@@ -1140,7 +1177,7 @@ __device__ __forceinline__ StepOut step_body(
   const double dg = var_on ? (q - gc) : 0.0;
   const double objv = gsum<G>(dg * dg) + (p0x - gx) * (p0x - gx) + (p0y - gy) * (p0y - gy);
   for (int wi = lane; wi < P.words; wi += G) lds_act[grp][wi] = 0ull;
-  __syncthreads();
+  wave_sync();
   if (have_sol) {
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
@@ -1155,7 +1192,7 @@ __device__ __forceinline__ StepOut step_body(
       }
     }
   }
-  __syncthreads();
+  wave_sync();
   if (valid && X) {
     const double nanv = NAN;
     if (var_on) {
@@ -1187,7 +1224,7 @@ __device__ __forceinline__ StepOut step_body(
 // kernel 1: one MPC step for B problems (lipmpc_plan_step_batch)
 // ------------------------------------------------------------------------------------------
 template <int G, int NOBS_L>
-__global__ __launch_bounds__(64) void plan_step_kernel(
+__global__ __launch_bounds__(WAVE) void plan_step_kernel(
     KArgs P, long B, const double* __restrict__ state, const double* __restrict__ goal,
     const int8_t* __restrict__ first_foot, const double* __restrict__ delta_in,
     const double* __restrict__ obs_xy, const int32_t* __restrict__ obs_nv,
@@ -1195,7 +1232,9 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
     double* __restrict__ omega_out, double* __restrict__ obj_out, int32_t* __restrict__ status_out,
     int32_t* __restrict__ iters_out, unsigned long long* __restrict__ active_out, double* __restrict__ c_eta,
     double* __restrict__ diag, const double* __restrict__ bounds) {
-  constexpr int GPW = 64 / G;
+  constexpr int GPW = WAVE / G;
+  static_assert(G == 16 || G == 32, "a problem is one or two DPP rows of one wavefront");
+  if (blockDim.x != WAVE) __builtin_trap();          // wave_sync() and every group exchange assume a one-wave workgroup
   const long prob_raw = (long)blockIdx.x * GPW + threadIdx.x / G;
   StepIn in;
   in.valid = prob_raw < B;
@@ -1221,13 +1260,14 @@ __global__ __launch_bounds__(64) void plan_step_kernel(
 // Each group owns one robot for the whole run: no host round trip, no batch-wide barrier per step.
 // ------------------------------------------------------------------------------------------
 template <int G, int NOBS_L>
-__global__ __launch_bounds__(64) void rollout_kernel(
+__global__ __launch_bounds__(WAVE) void rollout_kernel(
     KArgs P, long B, int k_max, int mpc_step, double stop_obj, const double* __restrict__ state0,
     const double* __restrict__ goal, const int8_t* __restrict__ first_foot, const double* __restrict__ delta_in,
     const double* __restrict__ obs_xy, const int32_t* __restrict__ obs_nv, double* __restrict__ X_pred,
     double* __restrict__ U_pred, int32_t* __restrict__ n_steps, int32_t* __restrict__ last_status,
     int32_t* __restrict__ total_iters, const double* __restrict__ bounds) {
-  constexpr int GPW = 64 / G;
+  constexpr int GPW = WAVE / G;
+  if (blockDim.x != WAVE) __builtin_trap();          // see plan_step_kernel
   const int lane = threadIdx.x & (G - 1);
   const long prob_raw = (long)blockIdx.x * GPW + threadIdx.x / G;
   StepIn in;
