@@ -3,9 +3,11 @@
 
 One "step" = one pass of the hot path (lipmpc_plan_step_batch: theta/omega, closest points,
 LDCBF rows, interior-point solve, certified active-set finish) over one batch of B synthetic
-problems already resident in HBM.  Workload = BASELINE configs[1]: B=4096 robots, N=8,
-10 convex-polygon obstacles, per GPU (weak scaling: N GPUs solve N*4096 independent problems,
-no data-path collective; RCCL only gathers the counters).
+problems already resident in HBM.
+  --gpus 1 : BASELINE configs[1]: B = 4096 robots, N = 8, 10 convex-polygon obstacles on one MI355X.
+  --gpus N>1: BASELINE configs[2]: ONE batch of 32768 robots sharded contiguously over the N ranks (16384 / 8192 / 4096
+              per GPU at N = 2 / 4 / 8: strong scaling of config 3), no data-path collective; RCCL only gathers the
+              counters.  --total-batch / --batch override either default (--batch = per GPU, weak scaling).
 
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -24,7 +26,19 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector = matrix peak (datasheet; not listed in the local guide)
+FP64_PEAK_DATASHEET = 78.6   # MI355X FP64 vector = matrix peak (datasheet: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz;
+                             # the local microarchitecture guide lists no FP64 figure)
+
+
+def fp64_peak():
+    """Measured FP64 vector FMA peak of this device class (tools/fp64_peak.hip, committed result in
+    profiles/r02_fp64_peak.json: 75.3 TFLOP/s with 4 waves per SIMD, 61.9 with the one wave per SIMD this kernel runs
+    at); the datasheet figure only if that file is missing."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_fp64_peak.json")))
+        return float(d["fp64_peak_tflops_measured"]), "measured (tools/fp64_peak.hip, profiles/r02_fp64_peak.json)", d
+    except Exception:
+        return FP64_PEAK_DATASHEET, "datasheet", None
 
 
 def f_iter(n, m):
@@ -37,7 +51,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=4096, help="problems per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="problems per GPU (weak scaling); default 4096 at --gpus 1")
+    ap.add_argument("--total-batch", type=int, default=0,
+                    help="problems in the whole job, sharded contiguously over the ranks (strong scaling); default 32768 at --gpus > 1")
     ap.add_argument("--horizon", type=int, default=8)
     ap.add_argument("--obstacles", type=int, default=10)
     ap.add_argument("--finish-rounds", type=int, default=0, help="lipmpc_params.finish_rounds (0 = library default)")
@@ -64,7 +80,14 @@ def main():
     synth = import_module("humanoid-navigation-using-mpc-ldcbf_amd.synth")
     sharding = import_module("humanoid-navigation-using-mpc-ldcbf_amd.sharding")
 
-    N, n_obs, B = args.horizon, args.obstacles, args.batch
+    N, n_obs = args.horizon, args.obstacles
+    # workload size: config 2 on one GPU; config 3 (one batch of 32768, contiguous shards) on several
+    if args.batch > 0:
+        B, total, scaling, lo = args.batch, args.batch * world, "weak", rank * args.batch
+    else:
+        total = args.total_batch if args.total_batch > 0 else (4096 if world == 1 else 32768)
+        lo, hi_ = sharding.shard_bounds(total, rank, world)
+        B, scaling = hi_ - lo, ("weak" if world == 1 else "strong")
     hi = 9.5 if N <= 8 else 15.5
     goal_xy = (10.0, 10.0) if N <= 8 else (16.0, 16.0)
     P = lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5, finish_rounds=args.finish_rounds)
@@ -72,7 +95,8 @@ def main():
     walker = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5, flags=lipmpc.FLAG_INTERIOR), local_rank)
 
     # ---- synthetic inputs (seeded per rank), placed in HBM before the timed region -------------
-    xy, nv = synth.synthetic_fields(B, n_obs, 0.5, hi, (0.0, 0.0), goal_xy, seed=1234 + rank)
+    # seeded per shard: rank r of a sharded job generates exactly its slice's fields (seed = first global index)
+    xy, nv = synth.synthetic_fields(B, n_obs, 0.5, hi, (0.0, 0.0), goal_xy, seed=1234 + lo)
     obs_xy = torch.as_tensor(xy, device=dev)
     obs_nv = torch.as_tensor(nv, device=dev)
     goal = torch.tensor([goal_xy], dtype=torch.float64, device=dev).repeat(B, 1).contiguous()
@@ -120,13 +144,23 @@ def main():
         fi = f_iter(2 * N, m_rows)
         flops_launch = float(fi * iters.astype(np.float64).sum())
         achieved = flops_launch / (kern_ms * 1e-3) / 1e12
-        traffic = None
+        peak, peak_src, peak_rec = fp64_peak()
+        # per-launch PMC figures of this exact workload, collected by tools/profile_round.sh in separate --pmc passes
+        # (HBM bytes: FETCH_SIZE / WRITE_SIZE; executed FP64 flops: SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 x 64 lanes)
+        traffic = executed = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"N{N}_obs{n_obs}_B{B}")
+                rec = json.load(open(tpath)).get(f"N{N}_obs{n_obs}_B{B}")
+                if isinstance(rec, dict):
+                    traffic, executed = rec.get("hbm_bytes"), rec.get("executed_fp64_flops")
+                else:
+                    traffic = rec
             except Exception:
-                traffic = None
+                pass
+        cfg_name = ("BASELINE configs[1]" if (N, n_obs, total, world) == (8, 10, 4096, 1) else
+                    "BASELINE configs[2]" if (N, n_obs, total) == (8, 10, 32768) else
+                    "BASELINE configs[3]" if (N, n_obs, total) == (16, 50, 4096) else "custom")
         res = {
             "metric": f"MPC-step QP solves/sec (batch) at N={N}, {n_obs} obstacles",
             "value": total_B * args.steps / t_max,
@@ -136,23 +170,32 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": t_max / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: B={B} robots per GPU, N={N}, {n_obs} convex-polygon obstacles "
+            "config": {"workload": f"{cfg_name}: {total} robots in all ({B} on rank 0), N={N}, {n_obs} convex-polygon obstacles "
                                    "(generate_obstacles distribution), states from closed-loop warm-up, delta in {0,0.3}",
-                       "batch_per_gpu": B, "horizon": N, "obstacles": n_obs, "parallelism": f"batch-shard x{world}"},
+                       "total_batch": total, "batch_rank0": B, "horizon": N, "obstacles": n_obs,
+                       "parallelism": f"contiguous batch shards x{world}, no data-path collective"},
             "solver": {"mean_iters": float(iters.mean()), "max_iters": int(iters.max()),
                        "status_hist": {str(k): int(v) for k, v in zip(*np.unique(status, return_counts=True))},
                        "solved_frac": n_ok / B},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic,
                          "kernel": "plan_step_kernel", "kernel_ms": kern_ms,
                          "flops_per_launch_algorithmic": flops_launch,
-                         "note": "compute-bound FP64 (vector FMA; peak = MI355X FP64 vector/matrix 78.6 TF datasheet); "
-                                 "achieved = SURVEY §8d dense F_iter x actual iterations / kernel time; the kernel "
-                                 "applies G structurally and executes far fewer flops (DESIGN.md)"},
+                         "executed_fp64_flops_per_launch": executed,
+                         "executed_tflops": (executed / (kern_ms * 1e-3) / 1e12) if executed else None,
+                         "executed_frac_of_peak": (executed / (kern_ms * 1e-3) / 1e12 / peak) if executed else None,
+                         "peak_source": peak_src, "peak_datasheet": FP64_PEAK_DATASHEET,
+                         "peak_one_wave_per_simd": (peak_rec or {}).get("fp64_fma_tflops", {}).get("1_wave_per_simd"),
+                         "note": "compute-bound FP64 on the vector ALU (no MFMA is issued: SQ_INSTS_VALU_MFMA_MOPS_F64 = 0); "
+                                 "achieved = SURVEY 8d DENSE algorithmic count F_iter(n,m) x the iterations each problem took "
+                                 "/ kernel time (HIP events on the launch stream); the kernel applies G through the "
+                                 "problem's structure and EXECUTES far fewer flops: executed_* are the FP64 VALU "
+                                 "instruction counters of the same launch (profiles/), a utilisation figure, whereas "
+                                 "frac prices the work a dense solver would do"},
         }
         if world == 1:
             res["rollout"] = rollout_throughput(lipmpc, walker, obs_xy, obs_nv, goal, delta, dev)
@@ -252,6 +295,16 @@ def other_configs(lipmpc, synth, dev):
     return out
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(P, state, goal, foot, obs_xy, obs_nv, delta, out):
     """The C oracle (dense port of the same algorithm) timed on this box's host cores on a bounded
     sample of the same workload.  Reported baseline only; it also re-checks the GPU result."""
@@ -287,16 +340,29 @@ def cpu_baseline(P, state, goal, foot, obs_xy, obs_nv, delta, out):
     du = float(np.max(np.abs(U[ok] - r1["U"][ok]))) if ok.any() else float("nan")
     # active sets, bit for bit, on the certified problems whose certificate is decisive (margin >= 1e-6: a weakly
     # active row may legitimately sit on either side)
+    # UNCERTIFIED answers (interior-point iterate handed out as usable) against the optimum the oracle certifies when its
+    # finish may run 64 rounds
+    unc = np.where(out["status"].cpu().numpy() == 4)[0]
+    du_unc, n_unc_cert = None, 0
+    if len(unc):
+        import dataclasses
+        P64 = dataclasses.replace(P, finish_rounds=64)
+        r64 = c_oracle.plan_step_batch(P64, st[unc], go[unc], fo[unc], xy[unc], nv[unc], de[unc], n_threads=cores)
+        c64 = r64["status"] == 0
+        n_unc_cert = int(c64.sum())
+        du_unc = float(np.max(np.abs(U[unc][c64] - r64["U"][c64]))) if c64.any() else None
     act_g = out["active"].cpu().numpy().view(np.uint64)
     firm = ok & (r1["diag"][:, 3] >= 1e-6)
     act_mism = int(np.sum(np.any(act_g[firm] != r1["active"][firm], axis=1)))
     return {"value": done / t_all, "unit": "solves/s", "cores": cores, "kind": "port",
             "sample": f"the same {B}-problem batch x {reps} passes, OpenMP over problems ({cores} threads); "
                       f"single thread: {B / t1:.0f} solves/s",
-            "value_1thread": B / t1,
+            "value_1thread": B / t1, "cpu_model": _cpu_model(),
             "max_abs_dU_gpu_vs_cpu": du,
             "status_mismatches": int(np.sum(r1["status"] != out["status"].cpu().numpy())),
-            "active_set_mismatches": act_mism, "active_sets_compared": int(firm.sum())}
+            "active_set_mismatches": act_mism, "active_sets_compared": int(firm.sum()),
+            "uncertified": int(len(unc)), "uncertified_certified_by_64_round_oracle": n_unc_cert,
+            "max_abs_dU_uncertified_vs_certified_optimum": du_unc}
 
 
 if __name__ == "__main__":
