@@ -218,23 +218,26 @@ __device__ __forceinline__ double fast_rcp(double x) {
   double y = __builtin_amdgcn_rcp(x);
   return fma(fma(-x, y, 1.0), y, y);
 }
+// reciprocal on the iteration's serial chain (step lengths, mu ratios)
+__device__ __forceinline__ double chain_rcp(double x) {
+#ifdef LIPMPC_IEEE_DIV
+  return 1.0 / x;
+#else
+  return fast_rcp(x);
+#endif
+}
 
 // acc + (value of `src` on lane J of the lane's DPP row) * mult in ONE instruction: v_fmac_f64 is the only FP64
 // arithmetic that takes a DPP operand on gfx950 (row_newbcast only), and the compiler never folds a
-// v_mov_b64_dpp into it, so it is written out.  Hazards the compiler would cover for its own DPP instructions are
-// covered by hand: a VGPR written by the previous VALU instruction needs 2 wait states before a DPP read
-// (s_nop 1); dpp_fence() before the first one of a sequence covers the 5 wait states after an EXEC write.
-#ifndef LIPMPC_DPP_NOP
-#define LIPMPC_DPP_NOP "s_nop 1\n\t"
-#endif
-template <int J> __device__ __forceinline__ double fmac_bcast(double acc, double src, double mult) {
-  asm(LIPMPC_DPP_NOP "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-      : "+v"(acc) : "v"(src), "v"(mult), "n"(J));
-  return acc;
-}
+// v_mov_b64_dpp into it, so it is written out.  Hazards, by hand (the compiler cannot see inside the asm):
+//  * a VGPR written by a VALU instruction needs 2 wait states before a DPP read (s_nop 1 in front of every fused
+//    operation whose DPP source may just have been written).  Measured on MI355X: with no wait state
+//    v_add_f64 -> v_fmac_f64_dpp reads the stale value on every lane (tools/dpp_hazard_test.hip), and a chain of
+//    dependent v_fmac_f64_dpp without wait states -- exact in that one-lane test -- returns garbage in the solver's
+//    substitution chains, where the broadcast lane moves along the row.  No link goes without its s_nop;
+//  * dpp_fence() before a sequence covers the 5 wait states after an EXEC write.
 template <int J> __device__ __forceinline__ double fmac_bcast_self(double acc, double mult) {
-  asm(LIPMPC_DPP_NOP "v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
-      : "+v"(acc) : "v"(mult), "n"(J));
+  asm("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(mult), "n"(J));
   return acc;
 }
 __device__ __forceinline__ void dpp_fence() { asm volatile("s_nop 4"); }
@@ -415,9 +418,16 @@ __device__ __forceinline__ StepOut step_body(
   sincos(th_v, &sv, &cv);
   const double foot_r = (a & 1) ? -foot0 : foot0;      // s_v[a]
   const double foot_v = -foot_r;                        // s_v[a+1]
-  // row vectors: reach row of this lane rr.(dp), velocity row wv.(v)
-  const double rr0 = c ? -sr : cr, rr1 = c ? cr : sr;
-  const double wv0 = c ? -sv : cv, wv1 = c ? cv * foot_v : sv;
+  // Row vectors in OWN / PARTNER form: lane (a, c) holds coordinate c of its stage ("own") and gets the other one from
+  // lane ^ 1 ("partner").  Reach row c of stage a: r = ro * d_own + rq * d_partner (R(theta) = [[cr, sr], [-sr, cr]]);
+  // velocity row c: w = wo * v_own + wq * v_partner (W = [[cv, sv], [-sv, cv s]]).  The transposes use (ro, -rq) and
+  // (wo, -wq).  Coefficients are ZERO on lanes without a variable (a >= N), so that every row map, transpose and K
+  // block of such a lane vanishes by itself: no select on c, a or var_on is left in the solver loops.
+  const double on = var_on ? 1.0 : 0.0;
+  const double ro = on * cr, rq = on * (c ? -sr : sr);
+  const double wo = on * (c ? cv * foot_v : cv), wq = on * (c ? -sv : sv);
+  const double cm = (c == 0) ? on : 0.0;          // the manoeuvrability row lives on the c = 0 lane of its stage
+  const double kap_l = on * kap;
 
   // ---- obstacles: c_j, eta_j at the current CoM (HumanoidMpc.py:296-319) ----------------------
   if (lane == 0) lds_flag[grp] = 0;
@@ -451,14 +461,18 @@ __device__ __forceinline__ StepOut step_body(
   wave_sync();
   const int front_flag = lds_flag[grp];
 
-  // per-lane LDCBF rows: obstacle j = 2t + c
-  double oex[NOBS_R > 0 ? NOBS_R : 1], oey[NOBS_R > 0 ? NOBS_R : 1], ob[NOBS_R > 0 ? NOBS_R : 1];
+  // per-lane LDCBF rows: obstacle j = 2t + c, h = oo * p_own + oq * p_partner - ob (eta in own / partner order);
+  // an absent slot is the constant row 0 . p - (-1) = 1
+  double oo[NOBS_R > 0 ? NOBS_R : 1], oq[NOBS_R > 0 ? NOBS_R : 1], ob[NOBS_R > 0 ? NOBS_R : 1];
   RowFlags pres;
 #pragma unroll
   for (int t = 0; t < NOBS_R; ++t) {
     const int j = 2 * t + c;
-    oex[t] = lds_obs[grp][j][0]; oey[t] = lds_obs[grp][j][1]; ob[t] = lds_obs[grp][j][2];
-    pres.set(R_CBF + t, var_on && (lds_obs[grp][j][3] != INFINITY));
+    const bool there = var_on && (lds_obs[grp][j][3] != INFINITY);
+    const double ex = lds_obs[grp][j][0], ey = lds_obs[grp][j][1];
+    oo[t] = there ? (c ? ey : ex) : 0.0; oq[t] = there ? (c ? ex : ey) : 0.0;
+    ob[t] = there ? lds_obs[grp][j][2] : -1.0;
+    pres.set(R_CBF + t, there);
   }
   // streamed rows: presence bits, accessors
   unsigned pbits = 0u;
@@ -478,54 +492,46 @@ __device__ __forceinline__ StepOut step_body(
   const double hi_v = c ? in.vmax_y : in.vmax_x, lo_v = P.v_min[c];
   const double hi_m = in.vmax_x - in.alpha_over_pi * fabs(om_a);
   // affine parts: reach r = rr.(p_{a+1} - p_a) + (c ? s_a*ell : 0); p_0 is a constant for a = 0
-  const double r_c = (c ? foot_r * P.ell : 0.0) - ((a == 0) ? (rr0 * p0x + rr1 * p0y) : 0.0);
+  const double p0q = c ? p0x : p0y, v0q = c ? v0x : v0y;          // partner coordinate of p_0, v_0
+  const double r_c = (c ? foot_r * P.ell : 0.0) - ((a == 0) ? (ro * p0c + rq * p0q) : 0.0);
   // v_{a+1} = kappa x_a + 2 kappa (-1)^a sum_{j<a} (-1)^j x_j + (-1)^{a+1} (v_0 + kappa p_0)
-  const double vcx = -sgn_a * (v0x + kap * p0x), vcy = -sgn_a * (v0y + kap * p0y);
-  const double w_c = wv0 * vcx + wv1 * vcy;
+  const double w_c = wo * (-sgn_a * (v0c + kap * p0c)) + wq * (-sgn_a * (v0q + kap * p0q));
 
   int n_rows_l = __popc(pbits);
 #pragma unroll
   for (int i = 0; i < NR; ++i) n_rows_l += pres[i] ? 1 : 0;
   const double m_rows = gsum<G>((double)n_rows_l);
+  const double inv_m = 1.0 / fmax(m_rows, 1.0);
 
   // ---- linear row maps -------------------------------------------------------------------------
   // rows(x): lin[R_RU] = rr.(x_a - x_{a-1}); lin[R_VU] = wv.v_a(x); lin[R_CBF+t] = eta_t . x_a
   auto rows_lin = [&](double x, double& r_lin, double& w_lin, double (&h_lin)[NOBS_R > 0 ? NOBS_R : 1], double& xx,
                       double& xy) {
     const double xp = gxor<G, 1>(x);
-    xx = c ? xp : x; xy = c ? x : xp;
-    double pxx = gup<G, 2>(xx, lane), pxy = gup<G, 2>(xy, lane);
-    if (a == 0) { pxx = 0.0; pxy = 0.0; }
-    r_lin = rr0 * (xx - pxx) + rr1 * (xy - pxy);
+    if constexpr (STREAM) { xx = c ? xp : x; xy = c ? x : xp; }      // streamed rows take (x, y) of the stage
+    const double dxo = x - gup<G, 2>(x, lane);                        // own coordinate of p_{a+1} - p_a (p_0 is in r_c)
+    r_lin = fma(rq, gxor<G, 1>(dxo), ro * dxo);
     const double ps = prefix_excl2<G>(sgn_a * x, lane);
     const double vl = kap * x + 2.0 * kap * sgn_a * ps;
-    const double vlp = gxor<G, 1>(vl);
-    const double vx = c ? vlp : vl, vy = c ? vl : vlp;
-    w_lin = wv0 * vx + wv1 * vy;
+    w_lin = fma(wq, gxor<G, 1>(vl), wo * vl);
 #pragma unroll
-    for (int t = 0; t < NOBS_R; ++t) h_lin[t] = oex[t] * xx + oey[t] * xy;
+    for (int t = 0; t < NOBS_R; ++t) h_lin[t] = fma(oq[t], xp, oo[t] * x);
   };
   // (G^T w)_lane from direction weights: tr (reach dir), tv (velocity dir), wc[t] (LDCBF rows, g = -eta)
   // (axs, ays): sum_t eta_t w_t over this lane's streamed rows
+  // (axs, ays): sum_t eta_t w_t over this lane's streamed rows, (x, y) order
   auto GT_apply = [&](double tr, double tv, const double (&wc)[NOBS_R > 0 ? NOBS_R : 1], double axs, double ays) -> double {
-    const double trp = gxor<G, 1>(tr);
-    const double t0 = c ? trp : tr, t1 = c ? tr : trp;
-    const double reach_own = c ? (sr * t0 + cr * t1) : (cr * t0 - sr * t1);
-    double reach_next = gdown<G, 2>(reach_own, lane);
-    if (a + 1 >= N) reach_next = 0.0;
-    double res = var_on ? (reach_own - reach_next) : 0.0;
-    const double tvp = gxor<G, 1>(tv);
-    const double u0 = c ? tvp : tv, u1 = c ? tv : tvp;
-    const double u = c ? (sv * u0 + cv * foot_v * u1) : (cv * u0 - sv * u1);
-    const double uu = var_on ? u : 0.0;
+    const double reach_own = fma(-rq, gxor<G, 1>(tr), ro * tr);
+    double res = reach_own - gdown<G, 2>(reach_own, lane);          // lanes past the last stage hold zeros
+    const double uu = fma(-wq, gxor<G, 1>(tv), wo * tv);
     const double suf = suffix_excl2<G>(sgn_a * uu, lane);
-    res += kap * uu + 2.0 * kap * sgn_a * suf;
-    double ax = axs, ay = ays;
+    res = fma(kap_l, uu, res);
+    res = fma(2.0 * kap_l * sgn_a, suf, res);
+    double aown = 0.0, apart = 0.0;                                   // eta-weighted sums for own / partner coordinate
+    if constexpr (STREAM) { aown = c ? ays : axs; apart = c ? axs : ays; }
 #pragma unroll
-    for (int t = 0; t < NOBS_R; ++t) { ax += oex[t] * wc[t]; ay += oey[t] * wc[t]; }
-    const double recv = gxor<G, 1>(c ? ax : ay);
-    res -= (c ? ay : ax) + recv;
-    return var_on ? res : 0.0;
+    for (int t = 0; t < NOBS_R; ++t) { aown = fma(oo[t], wc[t], aown); apart = fma(oq[t], wc[t], apart); }
+    return res - (aown + gxor<G, 1>(apart));
   };
 
   // ---- K = 2I + G^T D G (lane = row), square-root-free factorisation, solves -----------------------
@@ -545,17 +551,21 @@ __device__ __forceinline__ StepOut step_body(
     const double e0 = c ? dvp : dv, e1 = c ? dv : dvp;
     // E = Wv^T diag(e0,e1) Wv, Wv = [[cv,sv],[-sv,cv*s]]
     const double E00 = cv * cv * e0 + sv * sv * e1, E01 = cv * sv * e0 - sv * cv * foot_v * e1, E11 = sv * sv * e0 + cv * cv * e1;
-    double Ec0 = c ? E01 : E00, Ec1 = c ? E11 : E01;
-    if (!var_on) { Ec0 = 0.0; Ec1 = 0.0; }
+    const double Ec0 = on * (c ? E01 : E00), Ec1 = on * (c ? E11 : E01);
     const double S0 = suffix_excl2<G>(Ec0, lane), S1 = suffix_excl2<G>(Ec1, lane);
     const double k2 = kap * kap;
     const double Pc0 = 2.0 * k2 * Ec0 + 4.0 * k2 * S0, Pc1 = 2.0 * k2 * Ec1 + 4.0 * k2 * S1;
     lds_P[grp][a][c][0] = Pc0; lds_P[grp][a][c][1] = Pc1;
-    double cxx = cxs, cxy = cxys, cyy = cys;
+    // LDCBF block sum_t d_t eta eta^T of the stage: accumulated as (own own, own partner, partner partner); the two
+    // lanes of a stage hold the same three sums with own / partner swapped
+    double coo = c ? cys : cxs, cop = cxys, cpp = c ? cxs : cys;
 #pragma unroll
-    for (int t = 0; t < NOBS_R; ++t) { cxx += dc[t] * oex[t] * oex[t]; cxy += dc[t] * oex[t] * oey[t]; cyy += dc[t] * oey[t] * oey[t]; }
-    cxx += gxor<G, 1>(cxx); cxy += gxor<G, 1>(cxy); cyy += gxor<G, 1>(cyy);
-    const double Cc0 = c ? cxy : cxx, Cc1 = c ? cyy : cxy;
+    for (int t = 0; t < NOBS_R; ++t) {
+      const double do_ = dc[t] * oo[t];
+      coo = fma(do_, oo[t], coo); cop = fma(do_, oq[t], cop); cpp = fma(dc[t] * oq[t], oq[t], cpp);
+    }
+    coo += gxor<G, 1>(cpp); cop += gxor<G, 1>(cop);
+    const double Cc0 = c ? cop : coo, Cc1 = c ? coo : cop;
     // F_{a+1}, row c (0 past the last stage: lanes without rows have d = 0, hence F = 0)
     const double Fn0 = gdown<G, 2>(Fc0, lane), Fn1 = gdown<G, 2>(Fc1, lane);
     const double Dg0 = (c ? 0.0 : 2.0) - k2 * Ec0 + Fc0 + Fn0 + Cc0;
@@ -650,16 +660,10 @@ __device__ __forceinline__ StepOut step_body(
       // forward: b_l += Xl_l[j] b_j (lanes l > j); lane j's b is final after step j-1.  backward on x = w - ipiv acc:
       // x_l += Yu_l[j] x_j (lanes l < j), lane j final once the columns above it are done.  One instruction per step.
       dpp_fence();
-      static_for<0, NV - 1>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        b = fmac_bcast_self<j>(b, Xl[j]);
-      });
-      double x = b * ipiv;
-      static_rfor<NV, 1>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        x = fmac_bcast_self<j>(x, Yu[j]);
-      });
-      return x;
+      if constexpr (NV == 16) {
+        b = solve_forward_chain(b, Xl);
+        return solve_backward_chain(b * ipiv, Yu);
+      } else return b;
     } else if constexpr (G == 16) {
       // forward Lt w = b: w_j = b_j / p_j, b_l -= Lt[l][j] w_j (l > j); lane j's b is final after step j
       static_for<0, NV>([&](auto jc) {
@@ -729,7 +733,7 @@ __device__ __forceinline__ StepOut step_body(
   double q = var_on ? p0c : 0.0;
   double s[NR], z[NR], slk[NR];     // slack variable, multiplier, slack function value h - g.q
   double hl[NOBS_R > 0 ? NOBS_R : 1];
-  double cx_, cy_;                   // stage position / direction of the last rows_lin call (both coordinates)
+  double cx_ = 0.0, cy_ = 0.0;       // stage position / direction of the last rows_lin call, (x, y) order (streamed rows only)
   auto slack_values = [&](double x) {
     double r_lin, w_lin;
     rows_lin(x, r_lin, w_lin, hl, cx_, cy_);
@@ -744,7 +748,7 @@ __device__ __forceinline__ StepOut step_body(
   auto rows_dir = [&](double dx, double (&dl)[NR]) {
     double r_lin, w_lin;
     rows_lin(dx, r_lin, w_lin, hl, cx_, cy_);
-    dl[R_RU] = r_lin; dl[R_RL] = -r_lin; dl[R_VU] = w_lin; dl[R_VL] = -w_lin; dl[R_M] = w_lin;
+    dl[R_RU] = r_lin; dl[R_RL] = -r_lin; dl[R_VU] = w_lin; dl[R_VL] = -w_lin; dl[R_M] = cm * w_lin;
 #pragma unroll
     for (int t = 0; t < NOBS_R; ++t) dl[R_CBF + t] = -hl[t];
   };
@@ -762,8 +766,12 @@ __device__ __forceinline__ StepOut step_body(
   };
 
   slack_values(q);
+  // An absent row (empty obstacle slot, manoeuvrability on the c = 1 lane, lane without a variable) is the constant
+  // row 0 . q <= 1 with s = slk = 1, z = 0: its direction coefficients are zero, so r_p, ds, dz and its weights stay
+  // exactly zero through the iteration with ONE masked quantity, 1/s (below), instead of a mask on every product.
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
+    slk[i] = pres[i] ? slk[i] : 1.0;
     s[i] = pres[i] ? fmax(slk[i], IPM_S_FLOOR) : 1.0;
     z[i] = pres[i] ? IPM_Z0 : 0.0;
   }
@@ -815,7 +823,7 @@ __device__ __forceinline__ StepOut step_body(
       double mu_l = 0.0, rpmax_l = 0.0, zmax_l = 0.0;
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
-        rp[i] = (s[i] - slk[i]) * pm[i];
+        rp[i] = s[i] - slk[i];
         mu_l = fma(s[i], z[i], mu_l);
         rpmax_l = fmax(rpmax_l, fabs(rp[i]));
         zmax_l = fmax(zmax_l, z[i]);
@@ -837,7 +845,7 @@ __device__ __forceinline__ StepOut step_body(
         }
       }
       const double musum = gsum<G>(mu_l);
-      const double mu = musum / m_rows;
+      const double mu = musum * inv_m;
       {   // no-progress safeguard, a ramp in mu / mu_prev (oracle/lipmpc_oracle.py).  Both values live in LDS: one more
           // double kept in registers across the factorisation costs 5 % of the iteration in AGPR traffic.
         const double mu_prev = lds_mu[grp][0];
@@ -855,11 +863,10 @@ __device__ __forceinline__ StepOut step_body(
         // Reciprocals once per row and iteration; every later division becomes a multiply, and the
         // ratio tests run on -ds/s, -dz/z (largest ratio r => step 1/r) so they need no division.
         // 1/z only feeds a ratio test: the 4.5e-8-accurate hardware seed is enough there.
-        double is_[NR], iz_[NR];
+        double is_[NR];
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-          is_[i] = fast_rcp(s[i]);
-          iz_[i] = __builtin_amdgcn_rcp(fmax(z[i], 1e-300));
+          is_[i] = fast_rcp(s[i]) * pm[i];                  // 0 for an absent row: d, w, dz of that row vanish
           d[i] = z[i] * is_[i];
         }
         K_rows(d, cxs, cxys, cys);
@@ -876,18 +883,20 @@ __device__ __forceinline__ StepOut step_body(
 #pragma unroll
         for (int i = 0; i < NR; ++i) w[i] = fma(d[i], rp[i] - s[i], z[i]);
         const double dqa = solve(m2qg - GT_rows(w, axs, ays));
-        double dl[NR], dsa[NR], dza[NR];
+        double dl[NR], c2[NR];                             // c2 = ds_aff dz_aff: all the corrector needs of the predictor
         rows_dir(dqa, dl);
-        const double ax_ = cx_, ay_ = cy_;                  // predictor direction of this stage (both coordinates)
+        const double ax_ = cx_, ay_ = cy_;                  // predictor direction of this stage (streamed rows)
         double r_l = 1.0;                                  // largest of 1, -ds/s, -dz/z
-        double s1_l = 0.0, s2_l = 0.0;                     // sum(s dz + z ds), sum(ds dz): mu_aff is a polynomial in the step
+        double s2_l = 0.0;                                 // sum ds dz: mu_aff = ((1 - a) sum(s z) + a^2 sum(ds dz)) / m,
+                                                           // because s dz + z ds = -s z holds row by row for the predictor
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-          dsa[i] = (-rp[i] - dl[i]) * pm[i];
-          dza[i] = -d[i] * (s[i] + dsa[i]);               // -(s z + z ds)/s
-          r_l = fmax(r_l, fmax(-dsa[i] * is_[i], -dza[i] * iz_[i]));
-          s1_l = fma(s[i], dza[i], fma(z[i], dsa[i], s1_l));
-          s2_l = fma(dsa[i], dza[i], s2_l);
+          const double dsa = -rp[i] - dl[i];
+          const double t = dsa * is_[i];                    // ds/s; and -dz/z = (s + ds)/s = 1 + t, no 1/z needed
+          const double dza = -fma(d[i], dsa, z[i]);         // -(s z + z ds)/s
+          r_l = fmax(r_l, fmax(-t, 1.0 + t));
+          c2[i] = dsa * dza;
+          s2_l += c2[i];
         }
         if constexpr (STREAM) {                            // pass B
 #pragma unroll STREAM_UNROLL
@@ -896,13 +905,14 @@ __device__ __forceinline__ StepOut step_body(
             const double dsa_t = (-r.rp + (r.ex * ax_ + r.ey * ay_)) * r.pm;      // g = -eta
             const double dza_t = -r.d * (r.s + dsa_t);
             r_l = fmax(r_l, fmax(-dsa_t * r.is, -dza_t * __builtin_amdgcn_rcp(fmax(r.z, 1e-300))));
-            s1_l = fma(r.s, dza_t, fma(r.z, dsa_t, s1_l));
             s2_l = fma(dsa_t, dza_t, s2_l);
           }
         }
-        const double a_aff = 1.0 / gmax<G>(r_l);
-        const double mu_aff = fma(a_aff, fma(a_aff, gsum<G>(s2_l), gsum<G>(s1_l)), musum) / m_rows;
-        const double ratio = mu_aff / mu;
+        // reciprocals to 2e-15 (v_rcp_f64 + one Newton step) instead of IEEE divisions: five of them sat on the
+        // iteration's serial chain at ~10 dependent instructions each
+        const double a_aff = chain_rcp(gmax<G>(r_l));
+        const double mu_aff = fma(a_aff * a_aff, gsum<G>(s2_l), (1.0 - a_aff) * musum) * inv_m;
+        const double ratio = mu_aff * chain_rcp(mu);
         double sigma = ratio * ratio * ratio;
         sigma = fmax(sigma, lds_mu[grp][1]);      // no-progress safeguard: floor computed at the top of the iteration
         const double sigma_mu = sigma * mu;
@@ -910,7 +920,7 @@ __device__ __forceinline__ StepOut step_body(
         double rc[NR];
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-          rc[i] = (fma(s[i], z[i], dsa[i] * dza[i]) - sigma_mu) * pm[i];
+          rc[i] = fma(s[i], z[i], c2[i]) - sigma_mu;
           w[i] = fma(fma(z[i], rp[i], -rc[i]), is_[i], z[i]);
         }
         axs = 0.0; ays = 0.0;
@@ -932,9 +942,10 @@ __device__ __forceinline__ StepOut step_body(
         double ds[NR], dz[NR];
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-          ds[i] = (-rp[i] - dl[i]) * pm[i];
+          ds[i] = -rp[i] - dl[i];
           dz[i] = -fma(z[i], ds[i], rc[i]) * is_[i];
-          r_l = fmax(r_l, fmax(-ds[i] * is_[i], -dz[i] * iz_[i]));
+          // 1/z only feeds this ratio test: the 4.5e-8-accurate hardware seed is enough
+          r_l = fmax(r_l, fmax(-ds[i] * is_[i], -dz[i] * __builtin_amdgcn_rcp(fmax(z[i], 1e-300))));
         }
         // streamed rows: (ds, dz) of the combined direction, recomputed identically in passes E and F
         auto s_step = [&](const SRow& r, double& ds_t, double& dz_t) {
@@ -953,7 +964,7 @@ __device__ __forceinline__ StepOut step_body(
             r_l = fmax(r_l, fmax(-ds_t * r.is, -dz_t * __builtin_amdgcn_rcp(fmax(r.z, 1e-300))));
           }
         }
-        const double alpha = IPM_STEP_FRAC / gmax<G>(r_l);
+        const double alpha = IPM_STEP_FRAC * chain_rcp(gmax<G>(r_l));
         if (!done) {
           if constexpr (STREAM) {                          // pass F (before q moves: rows are evaluated at the old iterate)
 #pragma unroll STREAM_UNROLL

@@ -43,8 +43,7 @@ keep = LIB + ".keep"
 shutil.copy(LIB, keep)
 try:
     for n in names:
-        if n != "(current)":
-            shutil.copy(os.path.join(ROOT, "variants", n + ".so"), LIB)
+        shutil.copy(keep if n == "(current)" else os.path.join(ROOT, "variants", n + ".so"), LIB)
         subprocess.run([sys.executable, "-c", CHILD % (ROOT, n)], check=True)
 finally:
     shutil.copy(keep, LIB); os.remove(keep)
