@@ -612,7 +612,7 @@ __device__ __forceinline__ StepOut step_body(
         ok = ok && (pj > 0.0);
         const double ip = fast_rcp(pj);
         const double nf = zero_unless(ln > j, Krow[j] * -ip);
-        if (ln == j) ipiv = ip;
+        ipiv = (ln == j) ? ip : ipiv;
         Xl[j] = nf;
         if constexpr (NV == 16) FactorStep<j>::run(Krow, nf);
       } else if constexpr (G == 16) {
@@ -620,7 +620,7 @@ __device__ __forceinline__ StepOut step_body(
         ok = ok && (pj > 0.0);
         const double ip = fast_rcp(pj);
         const double f = zero_unless(ln > j, Krow[j] * ip);
-        if (ln == j) ipiv = ip;
+        ipiv = (ln == j) ? ip : ipiv;
         static_for<j + 1, NV>([&](auto cc_) {
           constexpr int cc = decltype(cc_)::value;
           Krow[cc] = fma(-f, gbcast<G, j>(Krow[cc]), Krow[cc]);
@@ -637,7 +637,7 @@ __device__ __forceinline__ StepOut step_body(
         // column.  (A Cholesky-form update g_l g_cc with g = S[.][j] / sqrt(p_j) keeps the two triangles bit-identical,
         // but breaks down -- pivot <= 0 -- on 3 % of the N=16 / 50-obstacle problems where this form does not.)
         const double ip = fast_rcp(pj);
-        if (ln == j) ipiv = ip;
+        ipiv = (ln == j) ? ip : ipiv;
         const double g = zero_unless(ln > j, Krow[j] * ip);
         static_for<j + 1, NV>([&](auto cc_) {
           constexpr int cc = decltype(cc_)::value;
@@ -773,7 +773,8 @@ __device__ __forceinline__ StepOut step_body(
   for (int i = 0; i < NR; ++i) {
     slk[i] = pres[i] ? slk[i] : 1.0;
     s[i] = pres[i] ? fmax(slk[i], IPM_S_FLOOR) : 1.0;
-    z[i] = pres[i] ? IPM_Z0 : 0.0;
+    z[i] = pres[i] ? IPM_Z0 : 1e-300;         // not 0: 1/z stays finite without a guard (a multiplier never reaches 0:
+                                              // every step keeps at least 0.005 of it)
   }
   if constexpr (STREAM) {
 #pragma unroll STREAM_UNROLL
@@ -945,7 +946,7 @@ __device__ __forceinline__ StepOut step_body(
           ds[i] = -rp[i] - dl[i];
           dz[i] = -fma(z[i], ds[i], rc[i]) * is_[i];
           // 1/z only feeds this ratio test: the 4.5e-8-accurate hardware seed is enough
-          r_l = fmax(r_l, fmax(-ds[i] * is_[i], -dz[i] * __builtin_amdgcn_rcp(fmax(z[i], 1e-300))));
+          r_l = fmax(r_l, fmax(-ds[i] * is_[i], -dz[i] * __builtin_amdgcn_rcp(z[i])));
         }
         // streamed rows: (ds, dz) of the combined direction, recomputed identically in passes E and F
         auto s_step = [&](const SRow& r, double& ds_t, double& dz_t) {
@@ -1064,7 +1065,7 @@ __device__ __forceinline__ StepOut step_body(
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
           const double r = act[i] ? -slk[i] : 0.0;      // G_A q - h_A
-          wr[i] = FIN_RHO * r;
+          wr[i] = -d[i] * slk[i];                       // rho r (d = rho on active rows, 0 elsewhere)
           rmax_l = fmax(rmax_l, fabs(r));
         }
         double ayx = 0.0, ayy = 0.0, awx = 0.0, awy = 0.0;
@@ -1093,7 +1094,7 @@ __device__ __forceinline__ StepOut step_body(
         if (!stop && !fin_done) {
           qf += dq;
 #pragma unroll
-          for (int i = 0; i < NR; ++i) if (act[i]) y[i] += FIN_RHO * (dl[i] - slk[i]);
+          for (int i = 0; i < NR; ++i) y[i] = fma(d[i], dl[i] - slk[i], y[i]);     // rho on active rows only
           if constexpr (STREAM) {
             const double ddx = cx_, ddy = cy_;
 #pragma unroll STREAM_UNROLL
@@ -1113,10 +1114,14 @@ __device__ __forceinline__ StepOut step_body(
       double ymin = INFINITY, smin = INFINITY;
       int yi = 0x7fffffff, si = 0x7fffffff;
 #pragma unroll
-      for (int i = 0; i < NR; ++i) {
+      for (int i = 0; i < NR; ++i) {                 // selects, no branches: (value, canonical index) lexicographic minima
         const int ci = ci_of(i);
-        if (act[i] && (y[i] < ymin || (y[i] == ymin && ci < yi))) { ymin = y[i]; yi = ci; }
-        if (pres[i] && !act[i] && (slk[i] < smin || (slk[i] == smin && ci < si))) { smin = slk[i]; si = ci; }
+        const bool ta = act[i], ti = pres[i] & !ta;
+        const double yv = ta ? y[i] : INFINITY, sv2 = ti ? slk[i] : INFINITY;
+        const bool by = (yv < ymin) | ((yv == ymin) & (ci < yi));
+        ymin = by ? yv : ymin; yi = by ? ci : yi;
+        const bool bs = (sv2 < smin) | ((sv2 == smin) & (ci < si));
+        smin = bs ? sv2 : smin; si = bs ? ci : si;
       }
       if constexpr (STREAM) {
         const double fx = cx_, fy = cy_;
@@ -1139,18 +1144,25 @@ __device__ __forceinline__ StepOut step_body(
       gargmin<G>(ymin, yi);
       gargmin<G>(smin, si);
       const double qabs = gmax<G>(fabs(qf));
+      {   // register rows: drop / add by selects (the groups of a wave take different arms)
+        const bool dropping = !fin_done & (ymin < -FIN_EPS);
+        const bool adding = !fin_done & !dropping & (smin < -FIN_EPS);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          const int ci = ci_of(i);
+          const bool hd = dropping & act[i] & (ci == yi), ha = adding & pres[i] & !act[i] & (ci == si);
+          y[i] = hd ? 0.0 : y[i];
+          act.m = (act.m & ~((unsigned)hd << i)) | ((unsigned)ha << i);
+        }
+      }
       if (!fin_done) {
         if (ymin < -FIN_EPS) {
-#pragma unroll
-          for (int i = 0; i < NR; ++i) if (act[i] && ci_of(i) == yi) { act.set(i, false); y[i] = 0.0; }
           if constexpr (STREAM) {
 #pragma unroll STREAM_UNROLL
             for (int t = 0; t < NOBS_S; ++t)
               if (((abits >> t) & 1u) && ci_s(t) == yi) { abits &= ~(1u << t); lds_sz[grp][t][lane][1] = 0.0; }
           }
         } else if (smin < -FIN_EPS) {
-#pragma unroll
-          for (int i = 0; i < NR; ++i) if (pres[i] && !act[i] && ci_of(i) == si) act.set(i, true);
           if constexpr (STREAM) {
 #pragma unroll STREAM_UNROLL
             for (int t = 0; t < NOBS_S; ++t)
