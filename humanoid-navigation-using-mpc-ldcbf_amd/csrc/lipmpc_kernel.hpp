@@ -812,7 +812,7 @@ __device__ __forceinline__ StepOut step_body(
   // multiplies per iteration instead of predicated selects everywhere
   double pm[NR];
 #pragma unroll
-  for (int i = 0; i < NR; ++i) pm[i] = pres[i] ? 1.0 : 0.0;
+  for (int i = 0; i < NR; ++i) pm[i] = pres[i] ? 2.0 : 1.0;      // the Newton constant of 1/s (below)
 
   // Groups of a wave leave the loop independently (real divergence: a finished group's lanes are
   // simply masked off; all exchanges inside are row-local DPP / group-local LDS).
@@ -867,7 +867,10 @@ __device__ __forceinline__ StepOut step_body(
         double is_[NR];
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-          is_[i] = fast_rcp(s[i]) * pm[i];                  // 0 for an absent row: d, w, dz of that row vanish
+          // 1/s by one Newton step on the hardware seed, y (c1 - s y) with c1 = 2; an absent row has s = 1 exactly
+          // (seed exact) and c1 = 1, which makes its 1/s exactly 0: d, w, dz of that row vanish at no extra cost
+          const double y0 = __builtin_amdgcn_rcp(s[i]);
+          is_[i] = y0 * fma(-s[i], y0, pm[i]);
           d[i] = z[i] * is_[i];
         }
         K_rows(d, cxs, cxys, cys);

@@ -81,30 +81,35 @@ static void closest_point_normal(const double* ring, int nv, double px, double p
 }
 
 /* ---- dense linear algebra ---------------------------------------------------------------- */
-static int cholesky(double* K, int n) { /* in place, lower; returns 0 on breakdown */
+/* Square-root-free factorisation K = L D L^T, right-looking, in place (lower triangle: L below the diagonal, D on it),
+ * and the two substitutions.  Same pivots as a Cholesky factorisation in exact arithmetic; in floating point it is the
+ * form the kernel uses, and it keeps going on badly conditioned K (cond ~ 1e16 in the last iterations of the N = 16 /
+ * 50-obstacle class) where the square-root form reports a non-positive pivot a step earlier -- with the square-root form
+ * here 5 of 4096 such problems came out INFEASIBLE that the kernel solves and certifies.  Returns 0 on a pivot <= 0. */
+static int cholesky(double* K, int n) {
   for (int j = 0; j < n; ++j) {
     double pj = K[j * n + j];
     if (!(pj > 0.0)) return 0;
-    double l = sqrt(pj);
-    K[j * n + j] = l;
-    for (int i = j + 1; i < n; ++i) K[i * n + j] /= l;
-    for (int c = j + 1; c < n; ++c) {
-      double lc = K[c * n + j];
-      for (int i = c; i < n; ++i) K[i * n + c] -= K[i * n + j] * lc;
+    double ip = 1.0 / pj;
+    for (int i = j + 1; i < n; ++i) {
+      double f = K[i * n + j] * ip;                 /* L_ij */
+      for (int c = j + 1; c <= i; ++c) K[i * n + c] -= f * K[c * n + j];
     }
+    for (int i = j + 1; i < n; ++i) K[i * n + j] *= ip;
   }
   return 1;
 }
 static void chol_solve(const double* L, int n, double* b) {
-  for (int j = 0; j < n; ++j) {
+  for (int j = 0; j < n; ++j) {                      /* L w = b (unit lower) */
     double s = b[j];
     for (int c = 0; c < j; ++c) s -= L[j * n + c] * b[c];
-    b[j] = s / L[j * n + j];
+    b[j] = s;
   }
-  for (int j = n - 1; j >= 0; --j) {
+  for (int j = 0; j < n; ++j) b[j] /= L[j * n + j]; /* D */
+  for (int j = n - 1; j >= 0; --j) {                 /* L^T x = w */
     double s = b[j];
     for (int i = j + 1; i < n; ++i) s -= L[i * n + j] * b[i];
-    b[j] = s / L[j * n + j];
+    b[j] = s;
   }
 }
 static void form_K(const double* G, const double* d, int m, int n, double* K) {
