@@ -21,7 +21,7 @@ class LipmpcParamsC(C.Structure):
 
 
 EXPORTS = ("lipmpc_default_params", "lipmpc_create", "lipmpc_destroy", "lipmpc_num_rows",
-           "lipmpc_active_words", "lipmpc_plan_step_batch", "lipmpc_advance_batch", "lipmpc_fleet_update_batch", "lipmpc_rollout_batch", "lipmpc_lidar_sense_batch",
+           "lipmpc_active_words", "lipmpc_plan_step_batch", "lipmpc_plan_step_batch_c_eta", "lipmpc_advance_batch", "lipmpc_fleet_update_batch", "lipmpc_rollout_batch", "lipmpc_lidar_sense_batch",
            "lipmpc_strerror", "lipmpc_version")
 
 _lib = None
@@ -50,6 +50,8 @@ def load():
     lib.lipmpc_active_words.restype = i64
     lib.lipmpc_plan_step_batch.argtypes = [vp, i64] + [vp] * 18
     lib.lipmpc_plan_step_batch.restype = i32
+    lib.lipmpc_plan_step_batch_c_eta.argtypes = [vp, i64] + [vp] * 16
+    lib.lipmpc_plan_step_batch_c_eta.restype = i32
     lib.lipmpc_advance_batch.argtypes = [vp, i64] + [vp] * 6
     lib.lipmpc_advance_batch.restype = i32
     lib.lipmpc_fleet_update_batch.argtypes = [vp, i64, C.c_int32, C.c_double] + [vp] * 17

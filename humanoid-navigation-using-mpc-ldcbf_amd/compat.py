@@ -63,6 +63,7 @@ class HumanoidMPC:
         self._interior_tol = interior_tol
         self._device = device
         self._solver = None
+        self._ce_solver = None
         self._rings = None
         self.last_status = None
 
@@ -79,7 +80,7 @@ class HumanoidMPC:
                          tol_interior=self._interior_tol)
         return BatchedLipMpc(p, self._device)
 
-    def _plan(self, state5, s0):
+    def _plan_rings(self, state5, s0):
         rings = self._get_obstacle_rings(state5[0], state5[2])
         n_obs = len(rings)
         v_max = max([3] + [len(r) for r in rings])
@@ -98,18 +99,59 @@ class HumanoidMPC:
         return {k: v[0].cpu().numpy() for k, v in out.items()}
 
     def _get_list_c_and_eta(self, x_k: float, y_k: float):
-        """HumanoidMpc.py:296-319 — (list_c, list_eta) of (2,1) arrays at the given CoM position."""
+        """HumanoidMpc.py:296-319 — (list_c, list_eta) of (2,1) arrays at the given CoM position (computed by the
+        kernel's geometry front end).  A subclass may override it, as the reference's unknown-environment variant does
+        (HumanoidMPCUnknownEnvironment.py:30-68): the step is then solved against the half-spaces it returns."""
         st = np.array([x_k, 0.0, y_k, 0.0, 0.0])
-        r = self._plan(st, 1)
+        r = self._plan_rings(st, 1)
         if "c_eta" not in r:
             return [], []
         return ([ce[:2].reshape(2, 1) for ce in r["c_eta"]], [ce[2:].reshape(2, 1) for ce in r["c_eta"]])
 
+    def _compute_single_lcbf(self, x, eta, c):
+        """HumanoidMpc.py:252-261 — h(x) = eta^T (x - c), numeric here (x, eta, c are (2,1) arrays).  A subclass may
+        override it with any function AFFINE in x (the reference's own override subtracts a margin,
+        HumanoidMPCCustomLCBF.py:30-31): the solver recovers the half-space from three evaluations."""
+        return float(np.asarray(eta, float).reshape(2) @ (np.asarray(x, float).reshape(2) - np.asarray(c, float).reshape(2)))
+
+    def _hooks_overridden(self):
+        t = type(self)
+        return (t._get_list_c_and_eta is not HumanoidMPC._get_list_c_and_eta
+                or t._compute_single_lcbf not in (HumanoidMPC._compute_single_lcbf, HumanoidMPCCustomLCBF._compute_single_lcbf))
+
+    def _plan(self, state5, s0):
+        """One MPC step.  Stock hooks: rings -> kernel front end.  Overridden hooks: the subclass's (c, eta) lists and
+        its h(x), turned into data for lipmpc_plan_step_batch_c_eta."""
+        if not self._hooks_overridden():
+            return self._plan_rings(state5, s0)
+        list_c, list_eta = self._get_list_c_and_eta(float(state5[0]), float(state5[2]))
+        rows = []
+        e0, e1, e2 = np.zeros((2, 1)), np.array([[1.0], [0.0]]), np.array([[0.0], [1.0]])
+        for c, eta in zip(list_c, list_eta):
+            h0 = float(self._compute_single_lcbf(e0, eta, c))
+            a = np.array([float(self._compute_single_lcbf(e1, eta, c)) - h0, float(self._compute_single_lcbf(e2, eta, c)) - h0])
+            n2 = float(a @ a)
+            if n2 > 0.0:                      # h(x) = a.x + h0 = a.(x - c') with c' = -h0 a / |a|^2
+                rows.append(np.concatenate([-h0 * a / n2, a]))
+        n_obs = len(rows)
+        if self._ce_solver is None or self._ce_solver.params.n_obs_max != n_obs:
+            p = LipMpcParams(N=self.N_horizon, n_obs_max=n_obs, v_max=3, sampling_time=self.sampling_time,
+                             flags=0 if self._exact else FLAG_INTERIOR, tol_interior=self._interior_tol)
+            self._ce_solver = BatchedLipMpc(p, self._device)
+        sv = self._ce_solver
+        dev = sv.device
+        t = lambda arr, dt: torch.as_tensor(np.ascontiguousarray(arr), dtype=dt, device=dev)
+        ce = t(np.array(rows).reshape(1, n_obs, 4) if n_obs else np.zeros((1, 0, 4)), torch.float64)
+        out = sv.plan_step_batch_c_eta(t(state5[None, :], torch.float64), t(np.asarray(self.goal, float)[None, :], torch.float64),
+                                       t(np.array([s0], np.int8), torch.int8), ce)
+        torch.cuda.synchronize(dev)
+        return {k: v[0].cpu().numpy() for k, v in out.items()}
+
     # -- the closed loop (HumanoidMpc.py:345-494) ------------------------------------------------
     def run_simulation(self, path_to_gif: str = None, make_fast_plot: bool = True, plot_animation: bool = False,
                        fill_animator: bool = True, initial_animator=None):
-        if type(self)._get_obstacle_rings is HumanoidMPC._get_obstacle_rings:
-            return self._run_on_device(initial_animator)       # static obstacles: whole loop in one launch
+        if type(self)._get_obstacle_rings is HumanoidMPC._get_obstacle_rings and not self._hooks_overridden():
+            return self._run_on_device(initial_animator)       # static obstacles, stock hooks: whole loop in one launch
         return self._run_stepwise(initial_animator)            # sensed / changing obstacles: one launch per sample
 
     def _run_on_device(self, initial_animator):
@@ -192,6 +234,10 @@ class HumanoidMPCCustomLCBF(HumanoidMPC):
         self.distance_from_obstacles = distance_from_obstacles
         super().__init__(goal, obstacles, N_horizon, N_mpc_timesteps, sampling_time,
                          np.zeros(5) if init_state is None else init_state, start_with_right_foot, verbosity, **kw)
+
+    def _compute_single_lcbf(self, x, eta, c):
+        """HumanoidMPCCustomLCBF.py:30-31 (the solver takes the margin as its `delta` input on the fast path)."""
+        return HumanoidMPC._compute_single_lcbf(self, x, eta, c) - self.distance_from_obstacles
 
 
 class HumanoidMPCWithRRT(HumanoidMPC):

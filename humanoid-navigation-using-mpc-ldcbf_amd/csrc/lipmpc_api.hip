@@ -128,18 +128,18 @@ void lipmpc_destroy(lipmpc_handle* h) { free(h); }
 
 #define LAUNCH(GG, NL)                                                                                         \
   launch_plan_step<GG, NL>(h->k, (long)B, state, goal, first_foot, delta, obs_xy, obs_nv, U, X, theta, omega, obj, \
-                           status, iters, (unsigned long long*)active, c_eta, diag, bounds, stream)
+                           status, iters, (unsigned long long*)active, c_eta, diag, bounds, c_eta_in, stream)
 
-int lipmpc_plan_step_batch(lipmpc_handle* h, int64_t B, const double* state, const double* goal,
-                           const int8_t* first_foot, const double* delta, const double* obs_xy,
-                           const int32_t* obs_nv, double* U, double* X, double* theta, double* omega,
-                           double* obj, int32_t* status, int32_t* iters, uint64_t* active, double* c_eta, double* diag,
-                           const double* bounds, void* hip_stream) {
+static int plan_step_impl(lipmpc_handle* h, int64_t B, const double* state, const double* goal,
+                          const int8_t* first_foot, const double* delta, const double* obs_xy,
+                          const int32_t* obs_nv, const double* c_eta_in, double* U, double* X, double* theta, double* omega,
+                          double* obj, int32_t* status, int32_t* iters, uint64_t* active, double* c_eta, double* diag,
+                          const double* bounds, void* hip_stream) {
   if (!h || B < 0) return LIPMPC_E_ARG;
   if (B == 0) return LIPMPC_OK;
   if (!state || !goal || !first_foot || !U || !X || !theta || !omega || !obj || !status || !iters || !active)
     return LIPMPC_E_ARG;
-  if (h->p.n_obs_max > 0 && (!obs_xy || !obs_nv)) return LIPMPC_E_ARG;
+  if (h->p.n_obs_max > 0 && !c_eta_in && (!obs_xy || !obs_nv)) return LIPMPC_E_ARG;
   if (hipSetDevice(h->device) != hipSuccess) return LIPMPC_E_HIP;
   hipStream_t stream = (hipStream_t)hip_stream;
   if (h->G == 16) {
@@ -162,6 +162,24 @@ int lipmpc_plan_step_batch(lipmpc_handle* h, int64_t B, const double* state, con
     }
   }
   return hipGetLastError() == hipSuccess ? LIPMPC_OK : LIPMPC_E_HIP;
+}
+
+int lipmpc_plan_step_batch(lipmpc_handle* h, int64_t B, const double* state, const double* goal,
+                           const int8_t* first_foot, const double* delta, const double* obs_xy,
+                           const int32_t* obs_nv, double* U, double* X, double* theta, double* omega,
+                           double* obj, int32_t* status, int32_t* iters, uint64_t* active, double* c_eta, double* diag,
+                           const double* bounds, void* hip_stream) {
+  return plan_step_impl(h, B, state, goal, first_foot, delta, obs_xy, obs_nv, nullptr, U, X, theta, omega, obj, status, iters,
+                        active, c_eta, diag, bounds, hip_stream);
+}
+
+int lipmpc_plan_step_batch_c_eta(lipmpc_handle* h, int64_t B, const double* state, const double* goal,
+                                 const int8_t* first_foot, const double* delta, const double* c_eta_in,
+                                 double* U, double* X, double* theta, double* omega, double* obj, int32_t* status,
+                                 int32_t* iters, uint64_t* active, double* diag, const double* bounds, void* hip_stream) {
+  if (h && h->p.n_obs_max > 0 && !c_eta_in) return LIPMPC_E_ARG;
+  return plan_step_impl(h, B, state, goal, first_foot, delta, nullptr, nullptr, c_eta_in, U, X, theta, omega, obj, status,
+                        iters, active, nullptr, diag, bounds, hip_stream);
 }
 
 #define LAUNCH_RO(GG, NL)                                                                                        \

@@ -356,7 +356,7 @@ __device__ __forceinline__ StepOut step_body(
     double* __restrict__ U, double* __restrict__ X, double* __restrict__ theta_out,
     double* __restrict__ omega_out, double* __restrict__ obj_out, int32_t* __restrict__ status_out,
     int32_t* __restrict__ iters_out, unsigned long long* __restrict__ active_out, double* __restrict__ c_eta,
-    double* __restrict__ diag) {
+    double* __restrict__ diag, const double* __restrict__ c_eta_in = nullptr) {
   constexpr int NMAX = G / 2;          // stages a group can hold
   constexpr int NV = G;                // variable slots (lanes)
   constexpr int GPW = 64 / G;          // groups per wavefront
@@ -439,12 +439,22 @@ __device__ __forceinline__ StepOut step_body(
         continue;
       }
       const long oidx = pb * P.n_obs + j;
-      const int nv = obs_nv[oidx];
       double cx = 0, cy = 0, ex = 0, ey = 0, bb = 0, h0 = INFINITY;
-      if (nv > 0) {
-        const ClosestPoint cp = closest_point_normal(obs_xy + oidx * P.nvert_max * 2, nv, p0x, p0y);
-        cx = cp.cx; cy = cp.cy; ex = cp.ex; ey = cp.ey;
-        const bool degen = cp.degenerate != 0;
+      bool there, degen = false;
+      if (c_eta_in) {      // caller-supplied half-spaces (the reference's _get_list_c_and_eta hook): eta = (0,0) = empty slot
+        const double* ce = c_eta_in + oidx * 4;
+        cx = ce[0]; cy = ce[1]; ex = ce[2]; ey = ce[3];
+        there = (ex != 0.0) || (ey != 0.0);
+      } else {
+        const int nv = obs_nv[oidx];
+        there = nv > 0;
+        if (there) {
+          const ClosestPoint cp = closest_point_normal(obs_xy + oidx * P.nvert_max * 2, nv, p0x, p0y);
+          cx = cp.cx; cy = cp.cy; ex = cp.ex; ey = cp.ey;
+          degen = cp.degenerate != 0;
+        }
+      }
+      if (there) {
         const double ec = ex * cx + ey * cy;
         bb = ec + delta;
         h0 = (ex * p0x + ey * p0y) - ec - delta;
@@ -1257,7 +1267,7 @@ __global__ __launch_bounds__(WAVE) void plan_step_kernel(
     double* __restrict__ U, double* __restrict__ X, double* __restrict__ theta_out,
     double* __restrict__ omega_out, double* __restrict__ obj_out, int32_t* __restrict__ status_out,
     int32_t* __restrict__ iters_out, unsigned long long* __restrict__ active_out, double* __restrict__ c_eta,
-    double* __restrict__ diag, const double* __restrict__ bounds) {
+    double* __restrict__ diag, const double* __restrict__ bounds, const double* __restrict__ c_eta_in) {
   constexpr int GPW = WAVE / G;
   static_assert(G == 16 || G == 32, "a problem is one or two DPP rows of one wavefront");
   if (blockDim.x != WAVE) __builtin_trap();          // wave_sync() and every group exchange assume a one-wave workgroup
@@ -1274,7 +1284,7 @@ __global__ __launch_bounds__(WAVE) void plan_step_kernel(
   in.foot0 = (double)first_foot[pb];
   in.delta = delta_in ? delta_in[pb] : 0.0;
   step_body<G, NOBS_L>(P, in, obs_xy, obs_nv, U, X, theta_out, omega_out, obj_out, status_out, iters_out, active_out,
-                       c_eta, diag);
+                       c_eta, diag, c_eta_in);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1358,7 +1368,8 @@ template <int G, int NOBS_L>
 void launch_plan_step(const KArgs& k, long B, const double* state, const double* goal, const int8_t* first_foot,
                       const double* delta, const double* obs_xy, const int32_t* obs_nv, double* U, double* X,
                       double* theta, double* omega, double* obj, int32_t* status, int32_t* iters,
-                      unsigned long long* active, double* c_eta, double* diag, const double* bounds, hipStream_t stream);
+                      unsigned long long* active, double* c_eta, double* diag, const double* bounds,
+                      const double* c_eta_in, hipStream_t stream);
 template <int G, int NOBS_L>
 void launch_rollout(const KArgs& k, long B, int k_max, int mpc_step, double stop_obj, const double* state0,
                     const double* goal, const int8_t* first_foot, const double* delta, const double* obs_xy,

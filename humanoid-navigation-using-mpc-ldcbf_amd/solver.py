@@ -104,7 +104,7 @@ class BatchedLipMpc:
             out["diag"] = torch.empty((B, 4), **f64)
         return out
 
-    def _check_inputs(self, state, goal, first_foot, obs_xy, obs_nv, delta):
+    def _check_inputs(self, state, goal, first_foot, obs_xy, obs_nv, delta, need_obstacles=True):
         P = self.params
         B = state.shape[0]
 
@@ -117,7 +117,7 @@ class BatchedLipMpc:
         need(state, (B, 5), torch.float64, "state")
         need(goal, (B, 2), torch.float64, "goal")
         need(first_foot, (B,), torch.int8, "first_foot")
-        if P.n_obs_max > 0:
+        if P.n_obs_max > 0 and need_obstacles:
             need(obs_xy, (B, P.n_obs_max, P.v_max, 2), torch.float64, "obs_xy")
             need(obs_nv, (B, P.n_obs_max), torch.int32, "obs_nv")
         if delta is not None:
@@ -133,8 +133,11 @@ class BatchedLipMpc:
         Returns dict(U,X,theta,omega,obj,status,iters,active[,c_eta]) of device tensors; results are
         valid once the current stream is synchronised."""
         B = self._check_inputs(state, goal, first_foot, obs_xy, obs_nv, delta)
+        self._check_optional(bounds, (B, 4), torch.float64, "bounds")
         if out is None:
             out = self.alloc_outputs(B, with_c_eta, with_diag)
+        else:
+            self._check_outputs(out, B)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = self.lib.lipmpc_plan_step_batch(
             self._h, B, _ptr(state), _ptr(goal), _ptr(first_foot), _ptr(delta), _ptr(obs_xy), _ptr(obs_nv),
@@ -143,6 +146,44 @@ class BatchedLipMpc:
             _ptr(out.get("diag")), _ptr(bounds), C.c_void_p(stream))
         _lib.check(rc, "lipmpc_plan_step_batch")
         return out
+
+    def plan_step_batch_c_eta(self, state, goal, first_foot, c_eta_in, delta=None, out=None, with_diag=False, bounds=None):
+        """The step with the LDCBF half-spaces given (lipmpc_plan_step_batch_c_eta): c_eta_in [B,n_obs_max,4] =
+        (c_x, c_y, eta_x, eta_y) per slot, eta = (0,0) = empty slot; row j of stage k is eta_j.(p_k - c_j) - delta >= 0.
+        This is what a subclass overriding the reference's _get_list_c_and_eta / _compute_single_lcbf hooks feeds."""
+        P = self.params
+        B = self._check_inputs(state, goal, first_foot, None, None, delta, need_obstacles=False)
+        if (c_eta_in is None or tuple(c_eta_in.shape) != (B, P.n_obs_max, 4) or c_eta_in.dtype != torch.float64
+                or c_eta_in.device != self.device or not c_eta_in.is_contiguous()):
+            raise ValueError(f"c_eta_in: expected contiguous float64 {(B, P.n_obs_max, 4)} on {self.device}")
+        self._check_optional(bounds, (B, 4), torch.float64, "bounds")
+        if out is None:
+            out = self.alloc_outputs(B, False, with_diag)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.lib.lipmpc_plan_step_batch_c_eta(
+            self._h, B, _ptr(state), _ptr(goal), _ptr(first_foot), _ptr(delta), _ptr(c_eta_in),
+            _ptr(out["U"]), _ptr(out["X"]), _ptr(out["theta"]), _ptr(out["omega"]), _ptr(out["obj"]),
+            _ptr(out["status"]), _ptr(out["iters"]), _ptr(out["active"]), _ptr(out.get("diag")), _ptr(bounds),
+            C.c_void_p(stream))
+        _lib.check(rc, "lipmpc_plan_step_batch_c_eta")
+        return out
+
+    def _check_optional(self, t, shape, dtype, name):
+        if t is not None and (tuple(t.shape) != shape or t.dtype != dtype or t.device != self.device or not t.is_contiguous()):
+            raise ValueError(f"{name}: expected contiguous {dtype} {shape} on {self.device}, got {t.dtype} {tuple(t.shape)} on {t.device}")
+
+    def _check_outputs(self, out, B, with_c_eta=False):
+        """caller-supplied output buffers must have the shapes alloc_outputs gives (raw pointers go to the kernel)"""
+        ref = {"U": ((B, self.params.N, 2), torch.float64), "X": ((B, self.params.N + 1, 4), torch.float64),
+               "theta": ((B, self.params.N + 1), torch.float64), "omega": ((B, self.params.N), torch.float64),
+               "obj": ((B,), torch.float64), "status": ((B,), torch.int32), "iters": ((B,), torch.int32),
+               "active": ((B, self.params.active_words), torch.int64)}
+        for k, (shape, dt) in ref.items():
+            if k not in out:
+                raise ValueError(f"out['{k}'] missing")
+            self._check_optional(out[k], shape, dt, f"out['{k}']")
+        self._check_optional(out.get("c_eta"), (B, self.params.n_obs_max, 4), torch.float64, "out['c_eta']")
+        self._check_optional(out.get("diag"), (B, 4), torch.float64, "out['diag']")
 
     def advance(self, state, first_foot, out):
         """In place: state <- (A_l x + B_l U[:,0], theta[:,1]), first_foot <- -first_foot for the

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LIPMPC_ABI_VERSION 1
+#define LIPMPC_ABI_VERSION 2   /* 2: + lipmpc_plan_step_batch_c_eta, LIPMPC_STATUS_SENSOR_OVERFLOW */
 
 /* per-problem status written to status[b] */
 #define LIPMPC_STATUS_SOLVED       0  /* exact optimum, KKT-certified active set */
@@ -116,6 +116,20 @@ int lipmpc_plan_step_batch(lipmpc_handle* h, int64_t B,
                            double* U, double* X, double* theta, double* omega, double* obj,
                            int32_t* status, int32_t* iters, uint64_t* active, double* c_eta, double* diag,
                            const double* bounds, void* hip_stream);
+
+/* The same step with the LDCBF half-spaces GIVEN instead of derived from obstacle rings: the reference's subclass
+ * hooks HumanoidMPC._get_list_c_and_eta(x_k, y_k) -> (list_c, list_eta) (HumanoidMpc.py:296-319; overridden by
+ * HumanoidMPCUnknownEnvironment.py:30-68) and _compute_single_lcbf(x, eta, c) (HumanoidMpc.py:252-261; overridden by
+ * HumanoidMPCCustomLCBF.py:30-31) as data.  Row j of every stage k is  eta_j . (p_k - c_j) - delta >= 0  with
+ *  c_eta_in [B,n_obs_max,4] (c_x, c_y, eta_x, eta_y); eta need not be a unit vector; eta = (0,0) marks an empty slot.
+ * Nothing of the geometry front end runs (no DEGENERATE status); the constant k = 0 row is still checked against k0_tol.
+ * Outputs as lipmpc_plan_step_batch (without c_eta). */
+int lipmpc_plan_step_batch_c_eta(lipmpc_handle* h, int64_t B,
+                                 const double* state, const double* goal, const int8_t* first_foot,
+                                 const double* delta, const double* c_eta_in,
+                                 double* U, double* X, double* theta, double* omega, double* obj,
+                                 int32_t* status, int32_t* iters, uint64_t* active, double* diag,
+                                 const double* bounds, void* hip_stream);
 
 /* Closed-loop state advance (HumanoidMpc.py:432-447): for problems with status SOLVED/UNCERTIFIED
  * state <- (A_l x + B_l U[b,0], theta[b,1]), first_foot <- -first_foot; others are left untouched.

@@ -25,12 +25,13 @@ def load():
             raise RuntimeError(f"{path} missing: run `make -C oracle` (or __graft_entry__.build())")
         _lib = C.CDLL(path)
         _lib.lipmpc_oracle_plan_step_batch.restype = C.c_int
-        _lib.lipmpc_oracle_plan_step_batch.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 17 + [C.c_int]
+        _lib.lipmpc_oracle_plan_step_batch.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 18 + [C.c_int]
         _lib.lipmpc_oracle_max_threads.restype = C.c_int
     return _lib
 
 
-def plan_step_batch(params, state, goal, first_foot, obs_xy=None, obs_nv=None, delta=None, n_threads=1, bounds=None):
+def plan_step_batch(params, state, goal, first_foot, obs_xy=None, obs_nv=None, delta=None, n_threads=1, bounds=None,
+                    c_eta_in=None):
     """params: LipMpcParams (host mirror of struct lipmpc_params).  numpy in, dict of numpy out."""
     lib = load()
     cp = params.to_c()
@@ -39,6 +40,7 @@ def plan_step_batch(params, state, goal, first_foot, obs_xy=None, obs_nv=None, d
     f = lambda a, dt: None if a is None else np.ascontiguousarray(a, dtype=dt)
     state, goal, first_foot = f(state, np.float64), f(goal, np.float64), f(first_foot, np.int8)
     obs_xy, obs_nv, delta, bounds = f(obs_xy, np.float64), f(obs_nv, np.int32), f(delta, np.float64), f(bounds, np.float64)
+    c_eta_in = f(c_eta_in, np.float64)
     out = dict(U=np.empty((B, N, 2)), X=np.empty((B, N + 1, 4)), theta=np.empty((B, N + 1)), omega=np.empty((B, N)),
                obj=np.empty(B), status=np.empty(B, np.int32), iters=np.empty(B, np.int32),
                active=np.zeros((B, words), np.uint64), c_eta=np.zeros((B, max(n_obs, 1), 4)), diag=np.zeros((B, 4)))
@@ -46,7 +48,7 @@ def plan_step_batch(params, state, goal, first_foot, obs_xy=None, obs_nv=None, d
     rc = lib.lipmpc_oracle_plan_step_batch(
         C.cast(C.byref(cp), C.c_void_p), B, p(state), p(goal), p(first_foot), p(delta), p(obs_xy), p(obs_nv),
         p(out["U"]), p(out["X"]), p(out["theta"]), p(out["omega"]), p(out["obj"]), p(out["status"]), p(out["iters"]),
-        p(out["active"]), p(out["c_eta"]) if n_obs else p(None), p(out["diag"]), p(bounds), int(n_threads))
+        p(out["active"]), p(out["c_eta"]) if n_obs else p(None), p(out["diag"]), p(bounds), p(c_eta_in), int(n_threads))
     if rc != 0:
         raise RuntimeError(f"lipmpc_oracle_plan_step_batch failed ({rc})")
     if not n_obs:

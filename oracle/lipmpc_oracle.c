@@ -161,7 +161,8 @@ typedef struct {
 /* One problem.  Layouts as in include/lipmpc.h. */
 static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, const double* st, const double* goal, int foot0, double delta,
                      const double* obs_xy, const int32_t* obs_nv, double* U, double* X, double* theta, double* omega,
-                     double* obj, int32_t* status_out, int32_t* iters_out, uint64_t* active, double* c_eta, double* diag) {
+                     double* obj, int32_t* status_out, int32_t* iters_out, uint64_t* active, double* c_eta, double* diag,
+                     const double* c_eta_in) {
   lipmpc_params Pl = *P0;   /* per-problem (V_MAX_x, V_MAX_y, ALPHA, OMEGA_MAX) overrides, bounds_tuning.py:17-26 */
   if (bnd) { Pl.v_max_xy[0] = bnd[0]; Pl.v_max_xy[1] = bnd[1]; Pl.alpha = bnd[2]; Pl.omega_max = bnd[3]; }
   const lipmpc_params* P = &Pl;
@@ -190,13 +191,18 @@ static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, cons
   int present[50];
   int flag = 0;
   for (int j = 0; j < n_obs; ++j) {
-    int nv = obs_nv[j];
-    present[j] = nv > 0;
     double cx = 0, cy = 0;
     ex[j] = ey[j] = bb[j] = 0.0;
-    if (nv > 0) {
-      int dg;
-      closest_point_normal(obs_xy + (size_t)j * P->v_max * 2, nv, p0[0], p0[1], &cx, &cy, &ex[j], &ey[j], &dg);
+    int dg = 0;
+    if (c_eta_in) {            /* given half-spaces (lipmpc_plan_step_batch_c_eta): eta = (0,0) = empty slot */
+      cx = c_eta_in[4 * j]; cy = c_eta_in[4 * j + 1]; ex[j] = c_eta_in[4 * j + 2]; ey[j] = c_eta_in[4 * j + 3];
+      present[j] = (ex[j] != 0.0) || (ey[j] != 0.0);
+    } else {
+      int nv = obs_nv[j];
+      present[j] = nv > 0;
+      if (nv > 0) closest_point_normal(obs_xy + (size_t)j * P->v_max * 2, nv, p0[0], p0[1], &cx, &cy, &ex[j], &ey[j], &dg);
+    }
+    if (present[j]) {
       double ec = ex[j] * cx + ey[j] * cy;
       bb[j] = ec + delta;
       double h0 = (ex[j] * p0[0] + ey[j] * p0[1]) - ec - delta;
@@ -424,7 +430,7 @@ int lipmpc_oracle_plan_step_batch(const lipmpc_params* P, int64_t B, const doubl
                                   const int8_t* first_foot, const double* delta, const double* obs_xy,
                                   const int32_t* obs_nv, double* U, double* X, double* theta, double* omega,
                                   double* obj, int32_t* status, int32_t* iters, uint64_t* active, double* c_eta,
-                                  double* diag, const double* bounds, int n_threads) {
+                                  double* diag, const double* bounds, const double* c_eta_in, int n_threads) {
   if (!P || P->N < 1 || P->N > 16 || P->n_obs_max < 0 || P->n_obs_max > 50) return LIPMPC_E_UNSUPPORTED;
   const int N = P->N, n_obs = P->n_obs_max;
   const int64_t words = (9 * N + (N + 1) * n_obs + 63) / 64;
@@ -444,7 +450,8 @@ int lipmpc_oracle_plan_step_batch(const lipmpc_params* P, int64_t B, const doubl
         plan_one(P, bounds ? bounds + b * 4 : NULL, W, state + b * 5, goal + b * 2, (int)first_foot[b], delta ? delta[b] : 0.0,
                  obs_xy ? obs_xy + (size_t)b * n_obs * P->v_max * 2 : NULL, obs_nv ? obs_nv + b * n_obs : NULL,
                  U + b * N * 2, X + b * (N + 1) * 4, theta + b * (N + 1), omega + b * N, obj + b, status + b, iters + b,
-                 active + b * words, c_eta ? c_eta + (size_t)b * n_obs * 4 : NULL, diag ? diag + b * 4 : NULL);
+                 active + b * words, c_eta ? c_eta + (size_t)b * n_obs * 4 : NULL, diag ? diag + b * 4 : NULL,
+                 c_eta_in ? c_eta_in + (size_t)b * n_obs * 4 : NULL);
       }
     }
     free(W);

@@ -582,3 +582,61 @@ def test_edge_shapes_and_ragged_inputs(golden_dir):
                              torch.zeros((0, 2), dtype=torch.float64, device="cuda"),
                              torch.zeros((0,), dtype=torch.int8, device="cuda"))
     assert out["U"].shape == (0, 3, 2)
+
+
+def test_given_half_spaces_entry_point_and_subclass_hooks(golden_dir):
+    """lipmpc_plan_step_batch_c_eta (the reference's _get_list_c_and_eta / _compute_single_lcbf hooks as data,
+    HumanoidMpc.py:252-261, 296-319): (1) fed with the c / eta the ring entry point reports, it returns the same bits;
+    (2) with arbitrary (non-unit) normals and empty slots it matches the C oracle given the same half-spaces;
+    (3) a subclass that subtracts a margin in _compute_single_lcbf the way HumanoidMPCCustomLCBF.py:30-31 does walks
+    the same trajectory as the class with distance_from_obstacles, and one that drops an obstacle in
+    _get_list_c_and_eta the trajectory of the scenario without that obstacle."""
+    import c_oracle
+    N, n_obs = 8, 10
+    probs = list(closed_loop_problems(N, n_obs, 4, 14, seed=21, delta=0.1))
+    B = len(probs)
+    P = lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5)
+    sv = lipmpc.BatchedLipMpc(P)
+    st = _dev(np.array([p[0] for p in probs]), torch.float64); goal = _dev(np.array([p[1] for p in probs], float), torch.float64)
+    foot = _dev(np.array([p[2] for p in probs], np.int8), torch.int8); delta = _dev(np.array([p[4] for p in probs], float), torch.float64)
+    xy, nv = lipmpc.pack_rings([p[3] for p in probs], n_obs, 5)
+    a = sv.plan_step_batch(st, goal, foot, _dev(xy, torch.float64), _dev(nv, torch.int32), delta, with_c_eta=True)
+    b = sv.plan_step_batch_c_eta(st, goal, foot, a["c_eta"].contiguous(), delta)
+    torch.cuda.synchronize()
+    for k in ("U", "X", "obj", "status", "iters", "active"):
+        assert torch.equal(a[k], b[k]) or (k in ("U", "X", "obj") and np.array_equal(a[k].cpu().numpy(), b[k].cpu().numpy(), equal_nan=True)), k
+    rng = np.random.default_rng(3)
+    ce = a["c_eta"].cpu().numpy().copy()
+    ce[:, :, 2:] *= rng.uniform(0.5, 2.0, (B, n_obs, 1))          # non-unit normals
+    ce[:, 7:, 2:] = 0.0                                            # three empty slots
+    g = sv.plan_step_batch_c_eta(st, goal, foot, _dev(ce, torch.float64), delta)
+    torch.cuda.synchronize()
+    ref = c_oracle.plan_step_batch(P, st.cpu().numpy(), goal.cpu().numpy(), foot.cpu().numpy(), None, None, delta.cpu().numpy(),
+                                   c_eta_in=ce, n_threads=8)
+    gs = g["status"].cpu().numpy()
+    assert np.array_equal(gs, ref["status"])
+    ok = gs == 0
+    assert ok.sum() > 0.8 * B and np.max(np.abs(g["U"].cpu().numpy()[ok] - ref["U"][ok])) < 1e-7
+    act = lipmpc.unpack_active(g["active"].cpu().numpy(), P.num_rows)
+    assert not act[:, 9 * N:].reshape(B, N + 1, n_obs)[:, :, 7:].any()       # rows of empty slots are never active
+    # (3) subclass hooks
+    obs = load_rings(os.path.join(golden_dir, "scenario_circles.npz"))
+    kw = dict(goal=(6, -3), N_horizon=3, N_mpc_timesteps=25, sampling_time=0.4, init_state=(0, 0, 3, 0, 0), verbosity=0)
+
+    class Margin(lipmpc.HumanoidMPC):
+        def _compute_single_lcbf(self, x, eta, c):
+            return super()._compute_single_lcbf(x, eta, c) - 0.3
+
+    class Blind(lipmpc.HumanoidMPC):
+        def _get_list_c_and_eta(self, x_k, y_k):
+            cs, etas = super()._get_list_c_and_eta(x_k, y_k)
+            return cs[:2], etas[:2]
+
+    Xm, Um, _ = Margin(obstacles=obs, **kw).run_simulation(None, make_fast_plot=False, fill_animator=False)
+    Xc, Uc, _ = lipmpc.HumanoidMPCCustomLCBF(obstacles=obs, distance_from_obstacles=0.3, **kw).run_simulation(None, make_fast_plot=False, fill_animator=False)
+    assert Xm.shape == Xc.shape and np.max(np.abs(Xm - Xc)) < 1e-7 and np.max(np.abs(Um - Uc)) < 1e-6
+    X0, U0, _ = lipmpc.HumanoidMPC(obstacles=obs, **kw).run_simulation(None, make_fast_plot=False, fill_animator=False)
+    assert np.max(np.abs(Xm - X0)) > 1e-3                                   # the margin really changes the walk
+    Xb, Ub, _ = Blind(obstacles=obs, **kw).run_simulation(None, make_fast_plot=False, fill_animator=False)
+    X2, U2, _ = lipmpc.HumanoidMPC(obstacles=obs[:2], **kw).run_simulation(None, make_fast_plot=False, fill_animator=False)
+    assert Xb.shape == X2.shape and np.max(np.abs(Xb - X2)) < 1e-7
