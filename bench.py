@@ -199,6 +199,9 @@ def main():
         }
         if world == 1:
             res["rollout"] = rollout_throughput(lipmpc, walker, obs_xy, obs_nv, goal, delta, dev)
+            warm_walker = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5,
+                                                                   flags=lipmpc.FLAG_INTERIOR | lipmpc.FLAG_WARM_START), local_rank)
+            res["rollout_warm_start"] = rollout_throughput(lipmpc, warm_walker, obs_xy, obs_nv, goal, delta, dev)
         if world == 1 and args.all_configs:
             res["other_configs"] = other_configs(lipmpc, synth, dev)
         if world == 1 and not args.no_cpu_baseline:

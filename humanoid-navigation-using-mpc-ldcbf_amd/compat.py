@@ -14,7 +14,8 @@ from typing import Union
 import numpy as np
 import torch
 
-from .solver import (BatchedLipMpc, LipMpcParams, FLAG_INTERIOR, STATUS_SOLVED, STATUS_UNCERTIFIED, pack_rings)
+from .solver import (BatchedLipMpc, LipMpcParams, FLAG_INTERIOR, FLAG_WARM_START, STATUS_SOLVED, STATUS_UNCERTIFIED,
+                     pack_rings)
 
 DELTA_T = 0.4  # config.yml:2
 
@@ -30,7 +31,7 @@ class HumanoidMPC:
     def __init__(self, goal, obstacles, N_horizon=3, N_mpc_timesteps=100, sampling_time=1e-3,
                  init_state: Union[np.ndarray, tuple] = np.array([0, 0, 0, 0, 0]),
                  start_with_right_foot: bool = True, verbosity: int = 1, *, exact: bool = False,
-                 interior_tol: float = 1e-6, device: int | None = None):
+                 interior_tol: float = 1e-6, warm_start: bool = False, device: int | None = None):
         # HumanoidMpc.py:66
         assert DELTA_T % sampling_time <= 1e-8, \
             "The sampling time must be lower than and divisible by the duration of the step."
@@ -61,6 +62,12 @@ class HumanoidMPC:
         # result figures (tests/golden/make_pdf_pins.py: run lengths, first steps).  Tighter values hug LDCBF
         # boundaries more closely than IPOPT does and end runs in front of walls early.
         self._interior_tol = interior_tol
+        # warm_start=True: every MPC step of the on-device loop starts from the previous step's shifted result (the
+        # reference seeds its next solve with the shifted prediction, HumanoidMpc.py:450-455): same optimum, 15-30 % fewer
+        # iterations.  Off by default: the interior iterate a step stops at depends on where it started, and the closed
+        # loops that reproduce the reference's figures (tests/golden/make_pdf_pins.py) are the cold-started ones -- the
+        # 7-sub-goal maze run ends in an infeasible corner 90 steps early when warm-started.
+        self._warm_start = warm_start
         self._device = device
         self._solver = None
         self._ce_solver = None
@@ -76,7 +83,8 @@ class HumanoidMPC:
 
     def _make_solver(self, n_obs, v_max):
         p = LipMpcParams(N=self.N_horizon, n_obs_max=n_obs, v_max=max(3, v_max),
-                         sampling_time=self.sampling_time, flags=0 if self._exact else FLAG_INTERIOR,
+                         sampling_time=self.sampling_time,
+                         flags=(0 if self._exact else FLAG_INTERIOR) | (FLAG_WARM_START if self._warm_start else 0),
                          tol_interior=self._interior_tol)
         return BatchedLipMpc(p, self._device)
 

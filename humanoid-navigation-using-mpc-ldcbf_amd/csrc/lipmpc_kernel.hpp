@@ -50,6 +50,8 @@ constexpr int FIN_ROUNDS_LONG = 10;      // ... and for longer horizons (worse c
 constexpr double FIN_IDENT = 1e5;   // initial working set z > FIN_IDENT * s: a deliberate under-estimate (oracle docstring)
 constexpr int FIN_INNER = 6;
 constexpr double FIN_INNER_TOL = 1e-11;
+constexpr double WARM_Z_MIN = 3.0, WARM_Z_MAX = 100.0;   // closed-loop warm start: band of the shifted previous multipliers
+constexpr int WARM_ROWS = 12;                            // register row slots a lane can hold (5 kinematic + 7 LDCBF)
 
 struct KArgs {
   int N, n_obs, nvert_max, max_iter, flags, fin_rounds;
@@ -340,6 +342,14 @@ struct StepOut {
   double ux, uy, theta1, omega0, obj;   // first footstep, next heading, first turning rate, objective
 };
 
+// Closed-loop warm start (LIPMPC_FLAG_WARM_START, rollout kernel): the interior-point result of a step, per lane, and
+// on the way in the start of the next one -- positions and multipliers shifted by one stage (oracle:
+// shift_warm_start; the reference seeds its next solve with the shifted prediction, HumanoidMpc.py:450-455).
+struct WarmIO {
+  bool have;                 // in: start from (q, z) instead of "stand still", z = 30
+  double q, z[WARM_ROWS];    // in: start; out: interior-point iterate and multipliers of this step
+};
+
 // per-problem overrides of (V_MAX_x, V_MAX_y, ALPHA, OMEGA_MAX) — the knobs bounds_tuning.py:17-26 sweeps
 __device__ __forceinline__ void load_bounds(const KArgs& P, const double* __restrict__ bounds, long pb, StepIn& in) {
   in.vmax_x = P.v_max[0]; in.vmax_y = P.v_max[1]; in.alpha_over_pi = P.alpha_over_pi; in.omega_max = P.omega_max;
@@ -356,7 +366,7 @@ __device__ __forceinline__ StepOut step_body(
     double* __restrict__ U, double* __restrict__ X, double* __restrict__ theta_out,
     double* __restrict__ omega_out, double* __restrict__ obj_out, int32_t* __restrict__ status_out,
     int32_t* __restrict__ iters_out, unsigned long long* __restrict__ active_out, double* __restrict__ c_eta,
-    double* __restrict__ diag, const double* __restrict__ c_eta_in = nullptr) {
+    double* __restrict__ diag, const double* __restrict__ c_eta_in = nullptr, WarmIO* __restrict__ warm = nullptr) {
   constexpr int NMAX = G / 2;          // stages a group can hold
   constexpr int NV = G;                // variable slots (lanes)
   constexpr int GPW = 64 / G;          // groups per wavefront
@@ -740,7 +750,8 @@ __device__ __forceinline__ StepOut step_body(
   };
 
   // ---- interior point ---------------------------------------------------------------------------
-  double q = var_on ? p0c : 0.0;
+  const bool warm_in = warm != nullptr && warm->have;       // wave-uniform
+  double q = var_on ? (warm_in ? warm->q : p0c) : 0.0;
   double s[NR], z[NR], slk[NR];     // slack variable, multiplier, slack function value h - g.q
   double hl[NOBS_R > 0 ? NOBS_R : 1];
   double cx_ = 0.0, cy_ = 0.0;       // stage position / direction of the last rows_lin call, (x, y) order (streamed rows only)
@@ -785,6 +796,7 @@ __device__ __forceinline__ StepOut step_body(
     s[i] = pres[i] ? fmax(slk[i], IPM_S_FLOOR) : 1.0;
     z[i] = pres[i] ? IPM_Z0 : 1e-300;         // not 0: 1/z stays finite without a guard (a multiplier never reaches 0:
                                               // every step keeps at least 0.005 of it)
+    if (warm_in && i < WARM_ROWS) z[i] = pres[i] ? warm->z[i] : 1e-300;
   }
   if constexpr (STREAM) {
 #pragma unroll STREAM_UNROLL
@@ -1001,6 +1013,11 @@ __device__ __forceinline__ StepOut step_body(
     }
   }
 
+  if (warm != nullptr) {                      // this step's interior-point result, for the caller to shift
+    warm->q = q;
+#pragma unroll
+    for (int i = 0; i < NR && i < WARM_ROWS; ++i) warm->z[i] = z[i];
+  }
   // canonical row index (include/lipmpc.h) of a local row slot / of streamed row t
   auto ci_of = [&](int i) -> int {
     if (i == R_RU) return 4 * a + c;
@@ -1322,6 +1339,13 @@ __global__ __launch_bounds__(WAVE) void rollout_kernel(
   bool fin = false;
   int k_done = 0, st_last = LIPMPC_STATUS_SOLVED, it_sum = 0;
   double last_obj = INFINITY, ukx = 0.0, uky = 0.0;
+  // warm start between MPC steps: register rows only (streamed instantiations start cold), horizons of 2 and more
+  constexpr bool CAN_WARM = NOBS_L <= 7;
+  const bool use_warm = CAN_WARM && (P.flags & LIPMPC_FLAG_WARM_START) && P.N >= 2;
+  WarmIO ws;
+  ws.have = false; ws.q = 0.0;
+#pragma unroll
+  for (int i = 0; i < WARM_ROWS; ++i) ws.z[i] = IPM_Z0;
   for (int k = 0; k < k_max; ++k) {
     if (!fin && last_obj < stop_obj) fin = true;
     if (__all(fin)) break;
@@ -1330,7 +1354,21 @@ __global__ __launch_bounds__(WAVE) void rollout_kernel(
       double theta1, omega0;
       if (is_mpc) {     // group-uniform (k and mpc_step are wave-uniform)
         const StepOut r = step_body<G, NOBS_L>(P, in, obs_xy, obs_nv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                               nullptr, nullptr, nullptr, nullptr);
+                                               nullptr, nullptr, nullptr, nullptr, nullptr, use_warm ? &ws : nullptr);
+        if (use_warm) {
+          // stage a takes over stage a+1 (positions: the last stage extrapolates one more step; multipliers: it keeps
+          // its own), multipliers clipped to the warm band; a failed solve ends the run anyway
+          const int a_ = lane >> 1;
+          const bool last = a_ >= P.N - 1;
+          const double qn = gdown<G, 2>(ws.q, lane), qp = gup<G, 2>(ws.q, lane);
+          ws.q = last ? (ws.q + (ws.q - qp)) : qn;
+#pragma unroll
+          for (int i = 0; i < WARM_ROWS; ++i) {
+            const double zn = gdown<G, 2>(ws.z[i], lane);
+            ws.z[i] = fmin(fmax(last ? ws.z[i] : zn, WARM_Z_MIN), WARM_Z_MAX);
+          }
+          ws.have = true;
+        }
         st_last = r.status;
         it_sum += r.iters;
         theta1 = r.theta1; omega0 = r.omega0;

@@ -14,6 +14,7 @@ from . import _lib
 STATUS_SOLVED, STATUS_MAX_ITER, STATUS_INFEASIBLE, STATUS_DEGENERATE, STATUS_UNCERTIFIED = 0, 1, 2, 3, 4
 STATUS_SENSOR_OVERFLOW = 5     # fleet loop only: a scan's clusters did not fit the obstacle slots
 FLAG_INTERIOR = 1
+FLAG_WARM_START = 2      # rollout: start every step from the previous step's shifted interior-point result
 
 
 @dataclass

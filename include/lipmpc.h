@@ -46,6 +46,12 @@ extern "C" {
 #define LIPMPC_FLAG_INTERIOR 1  /* skip the active-set finish: return the strictly interior
                                    interior-point iterate (what IPOPT hands the reference's loop) */
 
+#define LIPMPC_FLAG_WARM_START 2 /* lipmpc_rollout_batch: every MPC step of a robot's run starts from the previous step's
+                                   interior-point result shifted by one stage (positions; multipliers clipped to [3, 100])
+                                   instead of "stand still", z = 30 -- the reference seeds its next solve with the shifted
+                                   prediction, HumanoidMpc.py:450-455.  Same optimum, fewer iterations (-15..-30 %).
+                                   Ignored for more than 14 obstacle slots and for N = 1. */
+
 /* error codes */
 #define LIPMPC_OK            0
 #define LIPMPC_E_ARG        -1

@@ -352,9 +352,10 @@ FIN_ROUNDS_LONG = 10   # ... and for longer horizons
 FIN_IDENT = 1e5        # initial working set: z_i > FIN_IDENT * s_i (see finish_active_set)
 FIN_INNER = 6          # max multiplier iterations per equality solve
 FIN_INNER_TOL = 1e-11
+WARM_Z_MIN, WARM_Z_MAX = 3.0, 100.0   # warm start of a closed loop: previous multipliers, shifted by one stage, clipped to this band
 
 
-def solve_qp_ipm(G, h, g, q0, tol=1e-11, max_iter=60):
+def solve_qp_ipm(G, h, g, q0, tol=1e-11, max_iter=60, z0=None):
     """min |q-g|^2 s.t. G q <= h by Mehrotra predictor-corrector on the normal equations
     K = 2I + G^T diag(z/s) G (slack form G q + s = h, s,z > 0).  Start: q0 (the caller passes
     "stand still", p_k = p_0), s = max(h - G q0, 0.1), z = 30; sigma = (mu_aff/mu)^3, raised towards 0.5 after an
@@ -366,7 +367,7 @@ def solve_qp_ipm(G, h, g, q0, tol=1e-11, max_iter=60):
     if m == 0:
         return QPResult(q=g.copy(), z=np.zeros(0), s=np.zeros(0), status=STATUS_SOLVED, iters=0)
     s = np.maximum(h - G @ q, IPM_S_FLOOR)
-    z = np.full(m, IPM_Z0)
+    z = np.full(m, IPM_Z0) if z0 is None else np.array(z0, float).copy()      # z0: warm start (shift_warm_start)
     status = STATUS_MAX_ITER
     it = 0
     mu_prev = math.inf
@@ -493,10 +494,11 @@ def finish_active_set(G, h, g, res: QPResult, rounds_cap: int = 0):
     return q, yf, None, A, cap, None
 
 
-def solve_qp_exact(G, h, g, q0, tol=1e-11, max_iter=60, finish_rounds=0):
+def solve_qp_exact(G, h, g, q0, tol=1e-11, max_iter=60, finish_rounds=0, z0=None):
     """IPM, then the certified active-set finish.  status 4 = IPM converged but the finish did
     not certify within its round budget (the IPM point is returned)."""
-    res = solve_qp_ipm(G, h, g, q0, tol=tol, max_iter=max_iter)
+    res = solve_qp_ipm(G, h, g, q0, tol=tol, max_iter=max_iter, z0=z0)
+    res.z_ipm = res.z.copy()
     res.active = np.zeros(G.shape[0], bool)
     if res.status != STATUS_SOLVED or G.shape[0] == 0:
         return res
@@ -590,9 +592,28 @@ def recover_trajectory(q, x0, P: Params):
     return X, U
 
 
-def plan_step(state, goal, first_foot, obstacles, delta, P: Params, exact=True):
+def shift_warm_start(q_prev, z_prev, N, n_obs):
+    """Warm start of the next step of a closed loop from the previous step's interior-point result (what the
+    reference does with the primal part, HumanoidMpc.py:450-455: the next solve is seeded with the shifted previous
+    prediction): stage k takes over stage k+1's position and multipliers (canonical row order, k = 0 LDCBF rows
+    included as zeros), the last stage extrapolates its position by one more step and keeps its multipliers;
+    multipliers are clipped to [WARM_Z_MIN, WARM_Z_MAX] -- a fresh start is z = 30 everywhere."""
+    qp = np.asarray(q_prev, float).reshape(N, 2)
+    q0 = np.vstack([qp[1:], qp[-1] + (qp[-1] - qp[-2])]).ravel() if N >= 2 else qp.ravel().copy()
+    z = np.asarray(z_prev, float)
+    zs = z.copy()
+    for k in range(N - 1):
+        zs[4 * k:4 * k + 4] = z[4 * (k + 1):4 * (k + 1) + 4]                                  # reach
+        zs[4 * N + k] = z[4 * N + k + 1]                                                      # manoeuvrability
+        zs[5 * N + 4 * k:5 * N + 4 * k + 4] = z[5 * N + 4 * (k + 1):5 * N + 4 * (k + 1) + 4]  # velocity
+        zs[9 * N + (k + 1) * n_obs:9 * N + (k + 2) * n_obs] = z[9 * N + (k + 2) * n_obs:9 * N + (k + 3) * n_obs]   # LDCBF stage k+1 <- k+2
+    return q0, np.clip(zs, WARM_Z_MIN, WARM_Z_MAX)
+
+
+def plan_step(state, goal, first_foot, obstacles, delta, P: Params, exact=True, warm=None):
     """One MPC step.  state = (px,vx,py,vy,theta); first_foot = s_0 in {+1,-1};
-    obstacles = list of CCW rings (V_j,2).  Returns a dict mirroring the C ABI outputs."""
+    obstacles = list of CCW rings (V_j,2).  Returns a dict mirroring the C ABI outputs.
+    warm = (q0 [2N], z0 [canonical rows]) from shift_warm_start, or None for the cold start."""
     N = P.N
     x0 = np.asarray(state[:4], float)
     theta, omega = precompute_theta_omega(x0, state[4], goal, P)
@@ -617,9 +638,12 @@ def plan_step(state, goal, first_foot, obstacles, delta, P: Params, exact=True):
     keep[k0] = False
     Gs, hs = G[keep], h[keep]
     q0 = np.tile([x0[0], x0[2]], N)
+    z0 = None
+    if warm is not None:
+        q0, z0 = np.asarray(warm[0], float), np.asarray(warm[1], float)[keep]
     fin = P.finish_rounds if P.finish_rounds > 0 else (FIN_ROUNDS if N <= 8 else FIN_ROUNDS_LONG)
-    res = solve_qp_exact(Gs, hs, g, q0, tol=P.tol, max_iter=P.max_iter, finish_rounds=fin) if exact else \
-        solve_qp_ipm(Gs, hs, g, q0, tol=P.tol_interior, max_iter=P.max_iter)
+    res = solve_qp_exact(Gs, hs, g, q0, tol=P.tol, max_iter=P.max_iter, finish_rounds=fin, z0=z0) if exact else \
+        solve_qp_ipm(Gs, hs, g, q0, tol=P.tol_interior, max_iter=P.max_iter, z0=z0)
     out["status"], out["iters"], out["rounds"] = res.status, res.iters, res.rounds
     if res.status not in (STATUS_SOLVED, STATUS_UNCERTIFIED):
         return out
@@ -632,12 +656,16 @@ def plan_step(state, goal, first_foot, obstacles, delta, P: Params, exact=True):
     out["margin"] = res.margin
     out["cert_margin"] = res.cert_margin
     out["q"] = res.q
+    # interior-point state for the next step's warm start: positions and multipliers of the IPM phase, canonical rows
+    z_full = np.zeros(m_tot)
+    z_full[keep] = getattr(res, "z_ipm", res.z)
+    out["q_ipm"], out["z_ipm"] = getattr(res, "q_ipm", res.q), z_full
     return out
 
 
 def run_closed_loop(goal, obstacles, N_horizon=3, N_mpc_timesteps=100, sampling_time=0.4,
                     init_state=(0, 0, 0, 0, 0), start_with_right_foot=True, delta=0.0,
-                    params: Params | None = None, exact=False):
+                    params: Params | None = None, exact=False, warm_start=False):
     """HumanoidMpc.py:345-459 (``run_simulation`` without plotting): returns X_pred (5,K+1),
     U_pred (3,K) with the reference's truncation rule ``X[:, :k+1], U[:, :k]`` (:457-459).
 
@@ -654,6 +682,8 @@ def run_closed_loop(goal, obstacles, N_horizon=3, N_mpc_timesteps=100, sampling_
     X_pred[:, 0] = np.asarray(init_state, float)
     last_obj = math.inf
     u_keep = np.zeros(2)
+    warm = None
+    iters_log = []
     k = 0
     for k in range(num_inputs):
         is_mpc = (k % mpc_step) == 0
@@ -663,9 +693,12 @@ def run_closed_loop(goal, obstacles, N_horizon=3, N_mpc_timesteps=100, sampling_
         step_number = k // mpc_step
         s0 = foot_window(step_number, 0, start_with_right_foot)[0]
         if is_mpc:
-            r = plan_step(st, goal, s0, obstacles, delta, P, exact=exact)
+            r = plan_step(st, goal, s0, obstacles, delta, P, exact=exact, warm=warm if warm_start else None)
             if r["status"] not in (STATUS_SOLVED, STATUS_UNCERTIFIED):
                 break
+            iters_log.append(r["iters"])
+            if warm_start and P.N >= 2:
+                warm = shift_warm_start(r["q_ipm"], r["z_ipm"], P.N, len(obstacles))
             last_obj = r["obj"]
             u_keep = r["U"][0]
             theta1, omega0 = r["theta"][1], r["omega"][0]
@@ -680,4 +713,5 @@ def run_closed_loop(goal, obstacles, N_horizon=3, N_mpc_timesteps=100, sampling_
         else:
             X_pred[:4, k + 1] = st[:4]
         X_pred[4, k + 1] = theta1
+    run_closed_loop.last_iters = iters_log          # interior-point iterations per solve of the last call (diagnostics)
     return X_pred[:, :k + 1], U_pred[:, :k]

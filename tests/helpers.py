@@ -122,14 +122,15 @@ def pdf_compare(golden_dir, run, X, U):
     return out
 
 
-def oracle_pdf_run(golden_dir, run, tol=IPOPT_LIKE_TOL):
+def oracle_pdf_run(golden_dir, run, tol=IPOPT_LIKE_TOL, warm_start=False):
     sc = pdf_scenario(golden_dir, run)
     goals = sc["subgoals"] if sc["subgoals"] is not None else [sc["goal"]]
     X = U = None
     st = sc["init"]
     for g in goals:                      # HumanoidMPCWithRRT.py:155-181 hand-off; a single goal is the plain class
         xs, us = O.run_closed_loop(tuple(g), sc["rings"], N_horizon=sc["N"], N_mpc_timesteps=300, sampling_time=0.4,
-                                   init_state=st, delta=sc["delta"], exact=False, params=O.Params(tol_interior=tol))
+                                   init_state=st, delta=sc["delta"], exact=False, params=O.Params(tol_interior=tol),
+                                   warm_start=warm_start)
         st = tuple(xs[:, -1])
         X = xs if X is None else np.concatenate((X, xs), axis=1)
         U = us if U is None else np.concatenate((U, us), axis=1)

@@ -217,8 +217,8 @@ def test_subgoal_sequencing_matches_oracle_handoff(golden_dir):
     with pytest.raises(ImportError):
         lipmpc.HumanoidMPCWithRRT(goal=(6, -3), obstacles=obs, verbosity=0, **kw).run_simulation(None)
     # batched: robot 0 walks all three sub-goals, robot 1 two, robot 2 one
-    P = lipmpc.LipMpcParams(N=3, n_obs_max=len(obs), v_max=max(len(r) for r in obs), flags=lipmpc.FLAG_INTERIOR,
-                            tol_interior=IPOPT_LIKE_TOL)
+    P = lipmpc.LipMpcParams(N=3, n_obs_max=len(obs), v_max=max(len(r) for r in obs),
+                            flags=lipmpc.FLAG_INTERIOR, tol_interior=IPOPT_LIKE_TOL)
     sv = lipmpc.BatchedLipMpc(P)
     xy, nv = lipmpc.pack_rings([obs] * 3, P.n_obs_max, P.v_max)
     n_sub = torch.tensor([3, 2, 1], dtype=torch.int32)
@@ -640,3 +640,34 @@ def test_given_half_spaces_entry_point_and_subclass_hooks(golden_dir):
     Xb, Ub, _ = Blind(obstacles=obs, **kw).run_simulation(None, make_fast_plot=False, fill_animator=False)
     X2, U2, _ = lipmpc.HumanoidMPC(obstacles=obs[:2], **kw).run_simulation(None, make_fast_plot=False, fill_animator=False)
     assert Xb.shape == X2.shape and np.max(np.abs(Xb - X2)) < 1e-7
+
+
+def test_rollout_warm_start_matches_oracle_and_saves_iterations(golden_dir):
+    """LIPMPC_FLAG_WARM_START: every step of the on-device loop starts from the previous step's interior-point result
+    shifted by one stage (oracle: shift_warm_start / run_closed_loop(warm_start=True); the reference seeds its next solve
+    with the shifted prediction, HumanoidMpc.py:450-455).  Same trajectory as the oracle's warm-started loop, fewer
+    iterations than the cold loop on the same robots."""
+    obs = load_rings(os.path.join(golden_dir, "scenario_circles.npz"))
+    kw = dict(N_horizon=3, N_mpc_timesteps=300, sampling_time=0.4, init_state=(0, 0, 3, 0, 0))
+    mpc = lipmpc.HumanoidMPC(goal=(6, -3), obstacles=obs, verbosity=0, warm_start=True, **kw)
+    X, U, _ = mpc.run_simulation(None, make_fast_plot=False, fill_animator=False)
+    Xo, Uo = O.run_closed_loop((6, -3), obs, exact=False, params=O.Params(tol_interior=IPOPT_LIKE_TOL), warm_start=True, **kw)
+    it_warm_oracle = float(np.mean(O.run_closed_loop.last_iters))
+    n = min(12, X.shape[1], Xo.shape[1])
+    assert abs(X.shape[1] - Xo.shape[1]) <= 3 and np.max(np.abs(X[:, :n] - Xo[:, :n])) < 1e-6
+    assert np.hypot(X[0, -1] - 6, X[2, -1] + 3) < 0.3
+    # batch: 256 robots on random fields, N = 8, cold against warm, same robots
+    st, goal, foot, xy, nv = _rollout_inputs(256, 10, 5)
+    res = {}
+    for name, fl in (("cold", lipmpc.FLAG_INTERIOR), ("warm", lipmpc.FLAG_INTERIOR | lipmpc.FLAG_WARM_START)):
+        sv = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=8, n_obs_max=10, v_max=5, flags=fl))
+        ro = sv.rollout(_dev(st, torch.float64), _dev(goal, torch.float64), _dev(foot, torch.int8), _dev(xy, torch.float64),
+                        _dev(nv, torch.int32), None, k_max=40, mpc_step=1)
+        torch.cuda.synchronize()
+        res[name] = (int(ro["n_steps"].sum()), int(ro["total_iters"].sum()), ro["X_pred"].cpu().numpy(), ro["n_steps"].cpu().numpy())
+    per = {k: v[1] / v[0] for k, v in res.items()}
+    print("rollout iterations per step: cold %.2f, warm %.2f (oracle, circles, warm: %.2f)" % (per["cold"], per["warm"], it_warm_oracle))
+    assert per["warm"] < 0.95 * per["cold"]
+    assert abs(res["warm"][0] - res["cold"][0]) < 0.05 * res["cold"][0]          # the robots walk as far
+    both = (res["cold"][3] >= 5) & (res["warm"][3] >= 5)
+    assert np.max(np.abs(res["cold"][2][both, :3] - res["warm"][2][both, :3])) < 1e-4     # same optimum: first steps agree to the stop tolerance
