@@ -342,12 +342,13 @@ struct StepOut {
   double ux, uy, theta1, omega0, obj;   // first footstep, next heading, first turning rate, objective
 };
 
-// Closed-loop warm start (LIPMPC_FLAG_WARM_START, rollout kernel): the interior-point result of a step, per lane, and
-// on the way in the start of the next one -- positions and multipliers shifted by one stage (oracle:
-// shift_warm_start; the reference seeds its next solve with the shifted prediction, HumanoidMpc.py:450-455).
+// Closed-loop warm start (LIPMPC_FLAG_WARM_START, rollout kernel): the interior-point result of a step -- position and
+// multipliers per lane -- parked in LDS (row r of the group's block: lane-contiguous) until the next step reads it back
+// SHIFTED by one stage, i.e. from lane + 2 (oracle: shift_warm_start; the reference seeds its next solve with the
+// shifted prediction, HumanoidMpc.py:450-455).  In LDS rather than registers: the state is dead through the whole solve.
 struct WarmIO {
-  bool have;                 // in: start from (q, z) instead of "stand still", z = 30
-  double q, z[WARM_ROWS];    // in: start; out: interior-point iterate and multipliers of this step
+  double* lds;               // [1 + WARM_ROWS][G] doubles of this group, or nullptr: no warm start
+  bool have;                 // a previous step's result is parked there
 };
 
 // per-problem overrides of (V_MAX_x, V_MAX_y, ALPHA, OMEGA_MAX) — the knobs bounds_tuning.py:17-26 sweeps
@@ -750,8 +751,15 @@ __device__ __forceinline__ StepOut step_body(
   };
 
   // ---- interior point ---------------------------------------------------------------------------
-  const bool warm_in = warm != nullptr && warm->have;       // wave-uniform
-  double q = var_on ? (warm_in ? warm->q : p0c) : 0.0;
+  const bool warm_on = warm != nullptr && warm->lds != nullptr;         // wave-uniform
+  const bool warm_in = warm_on && warm->have;
+  const bool last_stage = a >= N - 1;
+  const int wsrc = last_stage ? lane : lane + 2;                          // stage a takes over stage a + 1; the last keeps its own
+  double q = var_on ? p0c : 0.0;
+  if (warm_in) {
+    const double qo = warm->lds[lane], qn = warm->lds[wsrc], qb = warm->lds[lane >= 2 ? lane - 2 : lane];
+    q = var_on ? (last_stage ? qo + (qo - qb) : qn) : 0.0;              // the last stage extrapolates one more step
+  }
   double s[NR], z[NR], slk[NR];     // slack variable, multiplier, slack function value h - g.q
   double hl[NOBS_R > 0 ? NOBS_R : 1];
   double cx_ = 0.0, cy_ = 0.0;       // stage position / direction of the last rows_lin call, (x, y) order (streamed rows only)
@@ -796,7 +804,7 @@ __device__ __forceinline__ StepOut step_body(
     s[i] = pres[i] ? fmax(slk[i], IPM_S_FLOOR) : 1.0;
     z[i] = pres[i] ? IPM_Z0 : 1e-300;         // not 0: 1/z stays finite without a guard (a multiplier never reaches 0:
                                               // every step keeps at least 0.005 of it)
-    if (warm_in && i < WARM_ROWS) z[i] = pres[i] ? warm->z[i] : 1e-300;
+    if (warm_in && i < WARM_ROWS) z[i] = pres[i] ? fmin(fmax(warm->lds[(1 + i) * G + wsrc], WARM_Z_MIN), WARM_Z_MAX) : 1e-300;
   }
   if constexpr (STREAM) {
 #pragma unroll STREAM_UNROLL
@@ -1013,10 +1021,12 @@ __device__ __forceinline__ StepOut step_body(
     }
   }
 
-  if (warm != nullptr) {                      // this step's interior-point result, for the caller to shift
-    warm->q = q;
+  if (warm_on) {                              // park this step's interior-point result for the next step
+    wave_sync();                              // (every lane has read its neighbours' previous values by now)
+    warm->lds[lane] = q;
 #pragma unroll
-    for (int i = 0; i < NR && i < WARM_ROWS; ++i) warm->z[i] = z[i];
+    for (int i = 0; i < NR && i < WARM_ROWS; ++i) warm->lds[(1 + i) * G + lane] = z[i];
+    wave_sync();
   }
   // canonical row index (include/lipmpc.h) of a local row slot / of streamed row t
   auto ci_of = [&](int i) -> int {
@@ -1139,7 +1149,7 @@ __device__ __forceinline__ StepOut step_body(
           }
         }
       }
-      slack_values(qf);
+      // (slk holds the slack functions of the final qf: every pass of the loop above evaluates them before it decides to stop)
       // most negative multiplier in A, most violated row outside A (lowest canonical index on ties)
       double ymin = INFINITY, smin = INFINITY;
       int yi = 0x7fffffff, si = 0x7fffffff;
@@ -1342,10 +1352,10 @@ __global__ __launch_bounds__(WAVE) void rollout_kernel(
   // warm start between MPC steps: register rows only (streamed instantiations start cold), horizons of 2 and more
   constexpr bool CAN_WARM = NOBS_L <= 7;
   const bool use_warm = CAN_WARM && (P.flags & LIPMPC_FLAG_WARM_START) && P.N >= 2;
+  __shared__ double lds_warm[GPW][1 + WARM_ROWS][G];
   WarmIO ws;
-  ws.have = false; ws.q = 0.0;
-#pragma unroll
-  for (int i = 0; i < WARM_ROWS; ++i) ws.z[i] = IPM_Z0;
+  ws.lds = use_warm ? &lds_warm[threadIdx.x / G][0][0] : nullptr;
+  ws.have = false;
   for (int k = 0; k < k_max; ++k) {
     if (!fin && last_obj < stop_obj) fin = true;
     if (__all(fin)) break;
@@ -1354,21 +1364,8 @@ __global__ __launch_bounds__(WAVE) void rollout_kernel(
       double theta1, omega0;
       if (is_mpc) {     // group-uniform (k and mpc_step are wave-uniform)
         const StepOut r = step_body<G, NOBS_L>(P, in, obs_xy, obs_nv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                               nullptr, nullptr, nullptr, nullptr, nullptr, use_warm ? &ws : nullptr);
-        if (use_warm) {
-          // stage a takes over stage a+1 (positions: the last stage extrapolates one more step; multipliers: it keeps
-          // its own), multipliers clipped to the warm band; a failed solve ends the run anyway
-          const int a_ = lane >> 1;
-          const bool last = a_ >= P.N - 1;
-          const double qn = gdown<G, 2>(ws.q, lane), qp = gup<G, 2>(ws.q, lane);
-          ws.q = last ? (ws.q + (ws.q - qp)) : qn;
-#pragma unroll
-          for (int i = 0; i < WARM_ROWS; ++i) {
-            const double zn = gdown<G, 2>(ws.z[i], lane);
-            ws.z[i] = fmin(fmax(last ? ws.z[i] : zn, WARM_Z_MIN), WARM_Z_MAX);
-          }
-          ws.have = true;
-        }
+                                               nullptr, nullptr, nullptr, nullptr, nullptr, &ws);
+        if (use_warm) ws.have = true;             // (a failed solve ends the run anyway)
         st_last = r.status;
         it_sum += r.iters;
         theta1 = r.theta1; omega0 = r.omega0;
