@@ -67,7 +67,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # LIPMPC_FORCE_DIST=1: initialise RCCL even at world size 1 (rehearsal of the N>1 code path on a one-GPU box)
     use_dist = world > 1 or os.environ.get("LIPMPC_FORCE_DIST") == "1"
+    real_stdout = None
     if use_dist:
+        # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout for the ONE JSON line
+        # (everything else, the banner included, goes to stderr until then)
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
@@ -206,7 +212,10 @@ def main():
             res["other_configs"] = other_configs(lipmpc, synth, dev)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(P, state, goal, foot, obs_xy, obs_nv, delta, out)
-        print(json.dumps(res))
+        if real_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(real_stdout, 1)
+        print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
