@@ -67,6 +67,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # LIPMPC_FORCE_DIST=1: initialise RCCL even at world size 1 (rehearsal of the N>1 code path on a one-GPU box)
     use_dist = world > 1 or os.environ.get("LIPMPC_FORCE_DIST") == "1"
+    # LIPMPC_BENCH_REHEARSE=1: the N>1 code path with the HIP solver on a ONE-GPU box (tests/test_sharding_gloo.py):
+    # every rank on device 0, gloo instead of RCCL (two RCCL ranks cannot share a GPU).  Never a measurement.
+    rehearse = os.environ.get("LIPMPC_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     real_stdout = None
     if use_dist:
         # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout for the ONE JSON line
@@ -76,8 +81,11 @@ def main():
         os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -143,7 +151,7 @@ def main():
     iters = out["iters"].cpu().numpy()
     n_ok = int(np.sum((status == 0) | (status == 4)))
     # RCCL all-gather of {seconds, problems, solved}: the only collective, after the timed region
-    t_max, total_B, total_ok, _ = sharding.gather_counters(elapsed, B, n_ok, device=dev)
+    t_max, total_B, total_ok, _ = sharding.gather_counters(elapsed, B, n_ok, device=None if rehearse else dev)
 
     if rank == 0:
         m_rows = 9 * N + N * n_obs
@@ -179,7 +187,7 @@ def main():
             "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo; not a measurement)" if rehearse else ""),
             "config": {"workload": f"{cfg_name}: {total} robots in all ({B} on rank 0), N={N}, {n_obs} convex-polygon obstacles "
                                    "(generate_obstacles distribution), states from closed-loop warm-up, delta in {0,0.3}",
                        "total_batch": total, "batch_rank0": B, "horizon": N, "obstacles": n_obs,

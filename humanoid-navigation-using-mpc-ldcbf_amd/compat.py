@@ -134,13 +134,22 @@ class HumanoidMPC:
             return self._plan_rings(state5, s0)
         list_c, list_eta = self._get_list_c_and_eta(float(state5[0]), float(state5[2]))
         rows = []
-        e0, e1, e2 = np.zeros((2, 1)), np.array([[1.0], [0.0]]), np.array([[0.0], [1.0]])
-        for c, eta in zip(list_c, list_eta):
-            h0 = float(self._compute_single_lcbf(e0, eta, c))
-            a = np.array([float(self._compute_single_lcbf(e1, eta, c)) - h0, float(self._compute_single_lcbf(e2, eta, c)) - h0])
-            n2 = float(a @ a)
-            if n2 > 0.0:                      # h(x) = a.x + h0 = a.(x - c') with c' = -h0 a / |a|^2
-                rows.append(np.concatenate([-h0 * a / n2, a]))
+        lcbf_stock = type(self)._compute_single_lcbf in (HumanoidMPC._compute_single_lcbf, HumanoidMPCCustomLCBF._compute_single_lcbf)
+        delta = None
+        if lcbf_stock:
+            # h(x) = eta.(x - c) - distance_from_obstacles: the hook's (c, eta) go to the solver as they are
+            rows = [np.concatenate([np.asarray(c, float).reshape(2), np.asarray(eta, float).reshape(2)]) for c, eta in zip(list_c, list_eta)]
+            delta = float(self.distance_from_obstacles)
+        else:
+            e0, e1, e2 = np.zeros((2, 1)), np.array([[1.0], [0.0]]), np.array([[0.0], [1.0]])
+            for c, eta in zip(list_c, list_eta):
+                h0 = float(self._compute_single_lcbf(e0, eta, c))
+                a = np.array([float(self._compute_single_lcbf(e1, eta, c)) - h0, float(self._compute_single_lcbf(e2, eta, c)) - h0])
+                n2 = float(a @ a)
+                if n2 > 0.0:                      # h(x) = a.x + h0 = a.(x - c') with c' = -h0 a / |a|^2
+                    rows.append(np.concatenate([-h0 * a / n2, a]))
+                elif n2 != n2:                    # NaN from the hook (degenerate geometry): let the solver report it
+                    rows.append(np.array([0.0, 0.0, np.nan, np.nan]))
         n_obs = len(rows)
         if self._ce_solver is None or self._ce_solver.params.n_obs_max != n_obs:
             p = LipMpcParams(N=self.N_horizon, n_obs_max=n_obs, v_max=3, sampling_time=self.sampling_time,
@@ -151,7 +160,8 @@ class HumanoidMPC:
         t = lambda arr, dt: torch.as_tensor(np.ascontiguousarray(arr), dtype=dt, device=dev)
         ce = t(np.array(rows).reshape(1, n_obs, 4) if n_obs else np.zeros((1, 0, 4)), torch.float64)
         out = sv.plan_step_batch_c_eta(t(state5[None, :], torch.float64), t(np.asarray(self.goal, float)[None, :], torch.float64),
-                                       t(np.array([s0], np.int8), torch.int8), ce)
+                                       t(np.array([s0], np.int8), torch.int8), ce,
+                                       None if delta is None else t(np.array([delta]), torch.float64))
         torch.cuda.synchronize(dev)
         return {k: v[0].cpu().numpy() for k, v in out.items()}
 

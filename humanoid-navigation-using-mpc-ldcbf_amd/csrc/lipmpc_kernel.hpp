@@ -452,10 +452,11 @@ __device__ __forceinline__ StepOut step_body(
       const long oidx = pb * P.n_obs + j;
       double cx = 0, cy = 0, ex = 0, ey = 0, bb = 0, h0 = INFINITY;
       bool there, degen = false;
-      if (c_eta_in) {      // caller-supplied half-spaces (the reference's _get_list_c_and_eta hook): eta = (0,0) = empty slot
+      if (c_eta_in) {      // caller-supplied half-spaces (the reference's _get_list_c_and_eta hook): eta = (0,0) = empty slot, NaN = degenerate
         const double* ce = c_eta_in + oidx * 4;
         cx = ce[0]; cy = ce[1]; ex = ce[2]; ey = ce[3];
         there = (ex != 0.0) || (ey != 0.0);
+        degen = (ex != ex) || (ey != ey);       // NaN normal: the producer met degenerate geometry (lipmpc_lidar_c_eta_batch)
       } else {
         const int nv = obs_nv[oidx];
         there = nv > 0;

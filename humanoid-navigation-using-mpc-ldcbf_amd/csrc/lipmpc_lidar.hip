@@ -5,9 +5,11 @@
 //       HumanoidNavigation/RangeFinder/range_finder_wth_polygons_dbscan.py:26-63, 65-83, 100-126, 157-180
 //   line_polygon_intersection (compute_intersection)      HumanoidNavigation/Utils/obstacles.py:95-139
 //   the call site                                          HumanoidNavigation/MPC/HumanoidMPCVariants/HumanoidMPCUnknownEnvironment.py:30-68
-// One wavefront (64 lanes) per robot; everything between the ray casting and the rings stays in LDS:
-//   1. rays: lane l owns rays l, l+64, ...; every ray walks obstacles in list order and edges in ring order and keeps
-//      the nearest hit strictly inside the range (contraction off: the hit points are bit-identical to the reference's)
+// One wavefront (64 lanes) per robot; everything between the ray casting and the half-spaces stays in LDS / registers:
+//   1. rays: lane l owns rays l, l+64, ...; the edges of the obstacles within range are staged once per robot in LDS
+//      (edge vector and the robot's offset from the edge's first vertex: the operands of compute_intersection, no
+//      global / scalar load left in the ray loops) and every ray walks them in list order, keeping the nearest hit
+//      strictly inside the range (contraction off: the hit points are bit-identical to the reference's)
 //   2. DBSCAN(eps, min_samples) by its order-free characterisation (oracle/lidar_oracle.py), on the readings
 //      compacted in ray order: neighbour bit rows, core flags, connected components of the core points (forest of
 //      "smallest core neighbour" pointers + pointer jumping, then merging trees through ballot masks of tree
@@ -16,6 +18,10 @@
 //   3. hull per cluster: Jarvis march from the lexicographically smallest point, farthest point on collinear ties
 //      (= the CCW ring of extreme points Qhull / monotone chain return, same rotation as np.unique + monotone chain);
 //      four clusters march at once, one per 16-lane DPP row, over compacted member lists
+//   4. constraint assembly (HumanoidMPCUnknownEnvironment.py:54-62 -> ObstaclesUtils.py:60-109): closest point c and
+//      unit normal eta of every hull at the robot's CoM, one hull edge per lane, from the hull still staged in LDS --
+//      the (c, eta) rows are what the step solver consumes (lipmpc_plan_step_batch_c_eta); the rings themselves go to
+//      HBM only when the caller asks for them
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -31,6 +37,8 @@ constexpr int NO_ROOT = 0x7fffffff;
 constexpr int SOLO_MIN = 48;        // a cluster of at least this many points gets the whole wave in the hull stage
 constexpr int NCC = 64;             // candidates whose bounding circle is kept for the per-pass sector test
 constexpr int VSTAGE = 64;          // hull vertices staged per cluster (v_max <= VSTAGE)
+constexpr int NRUN = RMAX / 16;      // runs of 16 consecutive readings
+constexpr int ECAP = 2 * RMAX / 4;  // edges staged per chunk of the ray phase (4 doubles each, in the hull stage's point arrays)
 static_assert(4 * VSTAGE * 2 <= 2 * RMAX, "hull staging reuses the point arrays");
 
 struct Cand { double x, y; int idx; };
@@ -50,21 +58,48 @@ __device__ __forceinline__ bool better(double px, double py, const Cand& a, cons
   return db > da || (db == da && b.idx < a.idx);
 }
 
+// closest point of one hull edge (a -> b) to p and the crossing test of the edge (prev -> a) with the +X ray from p:
+// the arithmetic of lipmpc_dev::closest_point_normal (ObstaclesUtils.py:50-109), one edge per call
+struct EdgeCp { double d, qx, qy; bool degen, hit; };
+__device__ __forceinline__ EdgeCp edge_closest(double pvx, double pvy, double ax, double ay, double bx, double by, double px,
+                                               double py) {
+#pragma clang fp contract(off)
+  EdgeCp r;
+  const double dx = bx - ax, dy = by - ay;
+  const double nrm = sqrt(dx * dx + dy * dy);
+  const double den = nrm * nrm;                      // sqrt-then-square, ObstaclesUtils.py:81
+  r.degen = den == 0.0;
+  double t = ((px - ax) * dx + (py - ay) * dy) / den;
+  t = fmax(0.0, fmin(1.0, t));
+  const double qx = ax + t * dx, qy = ay + t * dy;
+  const double ux = qx - px, uy = qy - py;
+  r.d = r.degen ? INFINITY : sqrt(ux * ux + uy * uy);
+  r.qx = r.degen ? NAN : qx; r.qy = r.degen ? NAN : qy;
+  const bool f0 = pvy >= py, f1 = ay >= py;
+  r.hit = (f0 != f1) && (((ay - py) * (pvx - ax) >= (ax - px) * (pvy - ay)) == f1);
+  return r;
+}
+
 __global__ __launch_bounds__(64) void lidar_sense_kernel(
     long B, int R, int n_env, int v_env, long env_stride, double lidar_range, double eps, int min_samples,
     int n_obs_max, int v_max, const double* __restrict__ state, const double* __restrict__ env_xy,
     const int32_t* __restrict__ env_nv, const double* __restrict__ ray_table, const double* __restrict__ noise,
-    double* __restrict__ obs_xy, int32_t* __restrict__ obs_nv, int32_t* __restrict__ n_inferred,
+    double* __restrict__ obs_xy, int32_t* __restrict__ obs_nv, double* __restrict__ c_eta, int32_t* __restrict__ n_inferred,
     int32_t* __restrict__ overflow, double* __restrict__ hits_out, int32_t* __restrict__ labels_out, int dbg_stop) {
-  __shared__ double pxy_[2 * RMAX];
+  __shared__ __attribute__((aligned(16))) double pxy_[2 * RMAX];
   double* const px_ = pxy_;
   double* const py_ = pxy_ + RMAX;
   __shared__ __attribute__((aligned(16))) int comp_[RMAX];                    // -1 = no reading; core: component root; else NO_ROOT
   __shared__ int root_[RMAX];                    // cluster root of every reading (NO_ROOT = noise)
-  __shared__ double cx_[RMAX], cy_[RMAX];       // points in member-list order (hull stage)
+  __shared__ __attribute__((aligned(16))) double cxy_[2 * RMAX];   // ray phase: staged edges; hull stage: points in member-list order
+  double* const cx_ = cxy_;
+  double* const cy_ = cxy_ + RMAX;
+  double* const edge_ = cxy_;                    // [ECAP][4]: (b - a) and (robot - a) of every staged edge
   __shared__ int roots_[64];
+  __shared__ int eoff_[65];                      // first staged edge of the chunk's candidates
   __shared__ double candc_[NCC][3];              // bounding circle (centre, radius) of the first NCC candidate obstacles
-  __shared__ double bb_[WORDS][4];               // bounding box (x0, x1, y0, y1) of the 64 points of each word
+  __shared__ double bb16_[NRUN][4];              // bounding box (x0, x1, y0, y1) of each run of 16 points
+  __shared__ unsigned nearm_[NRUN];              // runs within eps of run a, as bits
   __shared__ int cand_[RMAX];                    // obstacles that can be hit from here, list order
 
   const int lane = threadIdx.x;
@@ -107,58 +142,102 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
   if (n_cand > RMAX) { n_cand = RMAX; in_ovf = 1; }
   in_ovf = __any(in_ovf) ? 1 : 0;
   __syncthreads();
-  for (int i = lane; i < RMAX; i += 64) {
-    bool have = false;
-    double hx = 0.0, hy = 0.0;
-    if (i < R) {
+  // this lane's rays (i = lane + 64 p): direction b1 - a1, nearest hit so far.  A ray beyond the resolution has a zero
+  // direction: every denominator is 0, it never hits.
+  double rdx[WORDS], rdy[WORDS], inv_len2[WORDS], bd[WORDS], hx[WORDS], hy[WORDS];
+#pragma unroll
+  for (int p = 0; p < WORDS; ++p) {
 #pragma clang fp contract(off)
-      const double ex = x0 + lidar_range * ray_table[2 * i], ey = y0 + lidar_range * ray_table[2 * i + 1];
-      const double rdx = ex - x0, rdy = ey - y0;               // b1 - a1
-      double best_d = lidar_range;
-      const double inv_len2 = __builtin_amdgcn_rcp(rdx * rdx + rdy * rdy);
-      for (int jc = 0; jc < n_cand; ++jc) {
+    const int i = p * 64 + lane;
+    const bool on = i < R;
+    const double ex = x0 + lidar_range * (on ? ray_table[2 * i] : 0.0), ey = y0 + lidar_range * (on ? ray_table[2 * i + 1] : 0.0);
+    rdx[p] = on ? ex - x0 : 0.0; rdy[p] = on ? ey - y0 : 0.0;
+    inv_len2[p] = __builtin_amdgcn_rcp(rdx[p] * rdx[p] + rdy[p] * rdy[p]);
+    bd[p] = lidar_range; hx[p] = 0.0; hy[p] = 0.0;
+  }
+  // The candidates' edges go through LDS in chunks of at most 64 obstacles / ECAP edges (one chunk on ordinary maps):
+  // lane c stages candidate jc0 + c -- edge vector g = b2 - a2 and offset f = a1 - a2 of the ray origin, the two operands
+  // compute_intersection (Utils/obstacles.py:107-123) forms from the edge -- then every pass of 64 rays walks the staged
+  // edges in list order.  Hits are kept across chunks in registers.
+  for (int jc0 = 0; jc0 < n_cand;) {
+    const bool mine = jc0 + lane < n_cand;
+    const int j = mine ? cand_[jc0 + lane] : 0;
+    const int nv = mine ? min(env[j], v_env) : 0;
+    int incl = nv;                                   // inclusive prefix sum of the edge counts over the lanes
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_up(incl, m, 64); if (lane >= m) incl += o; }
+    const bool fits = mine && incl <= ECAP;          // a prefix of the lanes (incl is monotone)
+    int nfit = __popcll(__ballot(fits));
+    if (nfit == 0) { in_ovf = 1; nfit = 1; }         // one ring longer than ECAP edges: skipped and flagged
+    if (fits) {
+#pragma clang fp contract(off)
+      const double* ring = exy + (long)j * v_env * 2;
+      const int off = incl - nv;
+      eoff_[lane] = off;
+      double ax = nv > 0 ? ring[0] : 0.0, ay = nv > 0 ? ring[1] : 0.0;
+      const double fx0 = ax, fy0 = ay;
+      for (int e = 0; e < nv; ++e) {
+        const bool last = e + 1 == nv;
+        const double bx = last ? fx0 : ring[2 * (e + 1)], by = last ? fy0 : ring[2 * (e + 1) + 1];
+        double* o = edge_ + 4 * (off + e);
+        o[0] = bx - ax; o[1] = by - ay; o[2] = x0 - ax; o[3] = y0 - ay;
+        ax = bx; ay = by;
+      }
+      if (lane == nfit - 1) eoff_[nfit] = incl;
+    } else if (lane == 0) { eoff_[0] = 0; eoff_[1] = 0; }      // (only when nothing fitted)
+    __syncthreads();
+    for (int c = 0; c < nfit; ++c) {
+      const int e0 = eoff_[c], e1 = eoff_[c + 1];
+      const int jc = jc0 + c;
+      double wx = 0.0, wy = 0.0, cr2 = INFINITY;
+      if (jc < NCC) { wx = candc_[jc][0] - x0; wy = candc_[jc][1] - y0; const double cr = candc_[jc][2] + 1e-6; cr2 = cr * cr; }
+#pragma unroll
+      for (int p = 0; p < WORDS; ++p) {
+        if (p * 64 >= R) continue;
         // sector test: the 64 rays of this pass span 64 degrees; an obstacle none of them comes near (distance from
         // its bounding circle's centre to the ray segment > radius, with a margin far above the rounding of this
         // estimate) is skipped by the whole wave — its edges could not have produced a hit for any of these rays
-        if (jc < NCC) {
-          const double wx = candc_[jc][0] - x0, wy = candc_[jc][1] - y0, cr = candc_[jc][2] + 1e-6;
-          const double tt = fmin(1.0, fmax(0.0, (wx * rdx + wy * rdy) * inv_len2));
-          const double ddx = wx - tt * rdx, ddy = wy - tt * rdy;
-          if (!__any(ddx * ddx + ddy * ddy <= cr * cr)) continue;
+        {
+          const double tt = fmin(1.0, fmax(0.0, (wx * rdx[p] + wy * rdy[p]) * inv_len2[p]));
+          const double ddx = wx - tt * rdx[p], ddy = wy - tt * rdy[p];
+          if (!__any(ddx * ddx + ddy * ddy <= cr2)) continue;
         }
-        const int j = cand_[jc];
-        const int nv = min(env[j], v_env);
-        const double* ring = exy + (long)j * v_env * 2;
-        bool chave = false;
-        double cx = 0.0, cy = 0.0, cd = lidar_range;
-        for (int e = 0; e < nv; ++e) {
-          const double a2x = ring[2 * e], a2y = ring[2 * e + 1];
-          const int e1 = (e + 1 == nv) ? 0 : e + 1;
-          const double b2x = ring[2 * e1], b2y = ring[2 * e1 + 1];
-          const double denom = (b2y - a2y) * rdx - (b2x - a2x) * rdy;
+        for (int e = e0; e < e1; ++e) {
+#pragma clang fp contract(off)
+          const double gx = edge_[4 * e], gy = edge_[4 * e + 1], fx = edge_[4 * e + 2], fy = edge_[4 * e + 3];
+          const double denom = gy * rdx[p] - gx * rdy[p];
           if (denom == 0.0) continue;
-          const double nua = (b2x - a2x) * (y0 - a2y) - (b2y - a2y) * (x0 - a2x);
-          const double nub = rdx * (y0 - a2y) - rdy * (x0 - a2x);
-          // cheap conservative prefilter (no division): clearly outside [0,1] -> next edge; the reference's exact
-          // division test decides everything that survives
+          const double nua = gx * fy - gy * fx;
+          const double nub = rdx[p] * fy - rdy[p] * fx;
+          // 0 <= ua <= 1 and 0 <= ub <= 1 for ua = nua / denom, ub = nub / denom decided WITHOUT dividing: a correctly
+          // rounded quotient is >= 0 exactly when the signs agree (or the numerator is +-0) and <= 1 exactly when
+          // |numerator| <= |denominator| (a quotient above 1 is at least 1 + 2^-53 (1 + tiny) and rounds to 1 + 2^-52;
+          // the one unreachable exception: a negative quotient below 5e-324 in magnitude, which rounds to -0.0 >= 0).
+          // Only a ray that really hits the edge pays for the division that places the hit.
           const double ad = fabs(denom), sa = (denom > 0.0) ? nua : -nua, sb = (denom > 0.0) ? nub : -nub;
-          const double slack = ad * 1e-12;
-          if (sa < -slack || sb < -slack || sa > ad + slack || sb > ad + slack) continue;
-          const double ua = nua / denom;
-          const double ub = nub / denom;
-          if (ua >= 0.0 && ua <= 1.0 && ub >= 0.0 && ub <= 1.0) {
-            const double qx = x0 + ua * rdx, qy = y0 + ua * rdy;
+          if (sa >= 0.0 && sa <= ad && sb >= 0.0 && sb <= ad) {
+            const double ua = nua / denom;
+            const double qx = x0 + ua * rdx[p], qy = y0 + ua * rdy[p];
             const double dd = sqrt((qx - x0) * (qx - x0) + (qy - y0) * (qy - y0));
-            if (dd < cd) { cd = dd; cx = qx; cy = qy; chave = true; }
+            if (dd < bd[p]) { bd[p] = dd; hx[p] = qx; hy[p] = qy; }      // strictly nearer: ties keep the earlier edge
           }
         }
-        if (chave && cd <= lidar_range && cd < best_d) { best_d = cd; hx = cx; hy = cy; have = true; }
       }
-      if (have && noise) { hx = hx + noise[(b * R + i) * 2]; hy = hy + noise[(b * R + i) * 2 + 1]; }
     }
-    px_[i] = hx; py_[i] = hy;
+    __syncthreads();
+    jc0 += nfit;
+  }
+  in_ovf = __any(in_ovf) ? 1 : 0;
+#pragma unroll
+  for (int p = 0; p < WORDS; ++p) {
+#pragma clang fp contract(off)
+    const int i = p * 64 + lane;
+    const bool have = bd[p] < lidar_range;           // bd starts at the range and only ever gets strictly smaller
+    double qx = have ? hx[p] : 0.0, qy = have ? hy[p] : 0.0;
+    if (have && noise) { qx = qx + noise[(b * R + i) * 2]; qy = qy + noise[(b * R + i) * 2 + 1]; }
+    px_[i] = qx; py_[i] = qy;
     comp_[i] = have ? NO_ROOT : -1;
-    if (hits_out && i < R) { hits_out[(b * R + i) * 2] = have ? hx : NAN; hits_out[(b * R + i) * 2 + 1] = have ? hy : NAN; }
+    if (hits_out && i < R) { hits_out[(b * R + i) * 2] = have ? qx : NAN; hits_out[(b * R + i) * 2 + 1] = have ? qy : NAN; }
   }
   __syncthreads();
 
@@ -200,51 +279,94 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
     vmask[w] = left >= 64 ? ~0ull : (left <= 0 ? 0ull : ((1ull << left) - 1ull));
   }
   // row[k][w]: neighbour bits of point lane + 64 k against the 64 points of word w — kept in registers (the lane
-  // that computes a row is the only one that reads it), which keeps the LDS footprint at 19 KB = 8 waves per CU
+  // that owns a point is the only one that reads its row), which keeps the LDS footprint at 20 KB = 8 waves per CU.
+  // All-pairs is 147 k distance tests for 384 readings (it was the longest phase of the scan), so the sweep is pruned
+  // and each test made cheap:
+  //  * readings come in ray order, so a RUN of 16 consecutive points is a short piece of one obstacle's outline with a
+  //    small bounding box.  Run a is tested against word w only if its box comes within eps of the box of one of w's
+  //    four runs (a 24 x 24 bit matrix of run pairs, one lane per run, computed once); both box tests are conservative
+  //    (eps with a margin far above any rounding), so no neighbour pair is ever dropped;
+  //  * a visited (run, word) tile is computed COLUMN by column: every lane holds one point of word w in registers, the
+  //    run's point kk comes as one LDS broadcast read, one compare gives the 64 bits "points of word w within eps of
+  //    point kk" as a wave mask -- by symmetry row[k][w] of point kk -- and v_writelane drops it into lane kk:
+  //    8 VALU instructions per 64 pair tests, no bit insertion.  dx^2 + dy^2 does not depend on which of the two
+  //    points is subtracted from which, so the bits are those of the reference's distance test.
   unsigned long long row[WORDS][WORDS];
+  double wxr[WORDS], wyr[WORDS];                         // this lane's point of every word
+  double* const pint_ = cxy_;                            // [RMAX][2] interleaved copy of the points (the staged edges are dead)
 #pragma unroll
   for (int k = 0; k < WORDS; ++k) {
+    wxr[k] = px_[k * 64 + lane]; wyr[k] = py_[k * 64 + lane];
+    pint_[2 * (k * 64 + lane)] = wxr[k]; pint_[2 * (k * 64 + lane) + 1] = wyr[k];
 #pragma unroll
     for (int w = 0; w < WORDS; ++w) row[k][w] = 0ull;
   }
-  // bounding boxes of the words: two words whose boxes are more than eps apart along an axis hold no neighbour pair,
-  // and the whole 64 x 64 block is skipped by the wave (clusters are contiguous runs of rays, so most off-diagonal
-  // blocks go)
-  for (int w = 0; w < NW; ++w) {
-    const int i = w * 64 + lane;
-    const bool vi = comp_[i] >= 0;
-    double x0 = vi ? px_[i] : INFINITY, x1 = vi ? px_[i] : -INFINITY, y0 = vi ? py_[i] : INFINITY, y1 = vi ? py_[i] : -INFINITY;
-    for (int m = 1; m < 64; m <<= 1) {
-      x0 = fmin(x0, __shfl_xor(x0, m, 64)); x1 = fmax(x1, __shfl_xor(x1, m, 64));
-      y0 = fmin(y0, __shfl_xor(y0, m, 64)); y1 = fmax(y1, __shfl_xor(y1, m, 64));
-    }
-    if (lane == 0) { bb_[w][0] = x0; bb_[w][1] = x1; bb_[w][2] = y0; bb_[w][3] = y1; }
+#pragma unroll
+  for (int w = 0; w < WORDS; ++w) {                       // boxes of the runs (empty run: an empty box)
+    const bool vi = (vmask[w] >> lane) & 1ull;
+    double x0 = vi ? wxr[w] : INFINITY, x1 = vi ? wxr[w] : -INFINITY, y0 = vi ? wyr[w] : INFINITY, y1 = vi ? wyr[w] : -INFINITY;
+    x0 = fmin(x0, lipmpc_dev::row_xor<1>(x0)); x1 = fmax(x1, lipmpc_dev::row_xor<1>(x1)); y0 = fmin(y0, lipmpc_dev::row_xor<1>(y0)); y1 = fmax(y1, lipmpc_dev::row_xor<1>(y1));
+    x0 = fmin(x0, lipmpc_dev::row_xor<2>(x0)); x1 = fmax(x1, lipmpc_dev::row_xor<2>(x1)); y0 = fmin(y0, lipmpc_dev::row_xor<2>(y0)); y1 = fmax(y1, lipmpc_dev::row_xor<2>(y1));
+    x0 = fmin(x0, lipmpc_dev::row_xor<4>(x0)); x1 = fmax(x1, lipmpc_dev::row_xor<4>(x1)); y0 = fmin(y0, lipmpc_dev::row_xor<4>(y0)); y1 = fmax(y1, lipmpc_dev::row_xor<4>(y1));
+    x0 = fmin(x0, lipmpc_dev::row_xor<8>(x0)); x1 = fmax(x1, lipmpc_dev::row_xor<8>(x1)); y0 = fmin(y0, lipmpc_dev::row_xor<8>(y0)); y1 = fmax(y1, lipmpc_dev::row_xor<8>(y1));
+    if ((lane & 15) == 0) { double* o = bb16_[w * 4 + (lane >> 4)]; o[0] = x0; o[1] = x1; o[2] = y0; o[3] = y1; }
   }
   __syncthreads();
-  for (int k = 0; k < NW; ++k) {
-    const int i = k * 64 + lane;
-    int cnt = 0;
-    const bool vi = comp_[i] >= 0;
-    const double xi = px_[i], yi = py_[i];
-    const double kx0 = bb_[k][0], kx1 = bb_[k][1], ky0 = bb_[k][2], ky1 = bb_[k][3];
+  const double epsx = eps * (1.0 + 1e-6) + 1e-9;         // eps with a margin for the box tests
+  {   // run a = lane: which runs b come within eps of it (bit b)
+    unsigned nm = 0u;
+    const double* me = bb16_[lane < NRUN ? lane : 0];
+    const double ax0 = me[0] - epsx, ax1 = me[1] + epsx, ay0 = me[2] - epsx, ay1 = me[3] + epsx;
+#pragma unroll 4
+    for (int rb = 0; rb < NRUN; ++rb) {
+      const double* o = bb16_[rb];
+      if (o[0] <= ax1 && o[1] >= ax0 && o[2] <= ay1 && o[3] >= ay0) nm |= 1u << rb;
+    }
+    if (lane < NRUN) nearm_[lane] = nm;
+  }
+  __syncthreads();
+  // (lo, hi) with lane l (wave-uniform) replaced by the wave-uniform 64-bit mask.  v_writelane_b32 takes ONE scalar
+  // operand besides m0 (constant bus), so the lane select goes through m0, saved and restored around the pair.
+  auto wrlane64 = [](int& lo, int& hi, unsigned long long mask, int l) {
+    int keep;
+    asm("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\ts_mov_b32 m0, %2"
+        : "+v"(lo), "+v"(hi), "=&s"(keep)
+        : "s"((int)(unsigned)mask), "s"((int)(unsigned)(mask >> 32)), "s"(l));
+  };
+  for (int k = 0; k < NW; ++k) {                          // wave-uniform
+    unsigned nmk[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) nmk[a] = __builtin_amdgcn_readfirstlane(nearm_[k * 4 + a]);
 #pragma unroll
     for (int w = 0; w < WORDS; ++w) {
       if (w >= NW) continue;
-      if (bb_[w][0] - kx1 > eps || kx0 - bb_[w][1] > eps || bb_[w][2] - ky1 > eps || ky0 - bb_[w][3] > eps) continue;   // wave-uniform
-      // counted, unrolled sweep over all 64 slots of the word (loads pipeline; absent points are masked after)
-      unsigned long long bits = 0ull;
-#pragma unroll 16
-      for (int kk = 0; kk < 64; ++kk) {
-#pragma clang fp contract(off)
-        const double dx = xi - px_[w * 64 + kk], dy = yi - py_[w * 64 + kk];
-        bits |= (unsigned long long)(dx * dx + dy * dy <= eps2) << kk;
-      }
-      bits = vi ? (bits & vmask[w]) : 0ull;
-      cnt += __popcll(bits);
+      int lo = 0, hi = 0;                                 // the row words being assembled: lane kk gets the mask of column kk
 #pragma unroll
-      for (int k2 = 0; k2 < WORDS; ++k2) if (k2 == k) row[k2][w] = bits;     // k is wave-uniform
+      for (int a = 0; a < 4; ++a) {
+        if (((nmk[a] >> (4 * w)) & 0xFu) == 0u) continue; // run a of word k has no point near word w
+        const double* col = pint_ + 2 * (k * 64 + a * 16);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+#pragma clang fp contract(off)
+          const double dx = wxr[w] - col[2 * u], dy = wyr[w] - col[2 * u + 1];
+          const unsigned long long mask = __ballot(dx * dx + dy * dy <= eps2);
+          wrlane64(lo, hi, mask, a * 16 + u);
+        }
+      }
+      const unsigned long long bits = ((((unsigned long long)(unsigned)hi) << 32) | (unsigned)lo) & vmask[w];
+#pragma unroll
+      for (int k2 = 0; k2 < WORDS; ++k2) if (k2 == k) row[k2][w] = ((vmask[k2] >> lane) & 1ull) ? bits : 0ull;     // k is wave-uniform
     }
-    root_[i] = (vi && cnt >= min_samples) ? i : NO_ROOT;      // core points start as their own root
+  }
+  // core points (>= min_samples neighbours, the point itself included) start as their own root
+#pragma unroll
+  for (int k = 0; k < WORDS; ++k) {
+    if (k >= NW) continue;
+    const int i = k * 64 + lane;
+    int cnt = 0;
+#pragma unroll
+    for (int w = 0; w < WORDS; ++w) cnt += __popcll(row[k][w]);
+    root_[i] = (comp_[i] >= 0 && cnt >= min_samples) ? i : NO_ROOT;
   }
   __syncthreads();
   for (int i = lane; i < npad; i += 64) if (comp_[i] >= 0) comp_[i] = root_[i];
@@ -370,9 +492,11 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
   // every "best next vertex" reduction is four in-row DPP steps — no LDS crossbar, no cross-row traffic.  Vertices
   // are staged in LDS (the neighbour rows are dead by now) and committed in cluster order for proper polygons only.
   int n_out = 0, ovf = (n_clusters > 64 || in_ovf) ? 1 : 0;
-  double* oxy = obs_xy + b * (long)n_obs_max * v_max * 2;
-  int32_t* onv = obs_nv + b * (long)n_obs_max;
-  for (int k = lane; k < n_obs_max; k += 64) onv[k] = 0;
+  double* oxy = obs_xy ? obs_xy + b * (long)n_obs_max * v_max * 2 : nullptr;
+  int32_t* onv = obs_nv ? obs_nv + b * (long)n_obs_max : nullptr;
+  double* oce = c_eta ? c_eta + b * (long)n_obs_max * 4 : nullptr;
+  if (onv) for (int k = lane; k < n_obs_max; k += 64) onv[k] = 0;
+  if (oce) for (int k = lane; k < n_obs_max * 4; k += 64) oce[k] = 0.0;       // eta = (0, 0): empty slot
   const int nc = n_clusters < 64 ? n_clusters : 64;
   int* list_ = cand_;                                   // member lists, cluster after cluster (labels are written)
   int* coff_ = comp_;                                   // coff_[k] .. coff_[k+1]: members of cluster k
@@ -464,8 +588,35 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
       if (nv >= 3) {
         if (n_out >= n_obs_max || nv > v_max) ovf = 1;
         else {
-          for (int v = lane; v < nv * 2; v += 64) oxy[(long)n_out * v_max * 2 + v] = stage_[qq * VSTAGE * 2 + v];
-          if (lane == 0) onv[n_out] = nv;
+          const double* ring = stage_ + qq * VSTAGE * 2;
+          if (oxy) for (int v = lane; v < nv * 2; v += 64) oxy[(long)n_out * v_max * 2 + v] = ring[v];
+          if (onv && lane == 0) onv[n_out] = nv;
+          if (oce) {
+            // ---- 4. constraint assembly: closest point c and unit normal eta of this hull at the CoM, one edge per lane
+            // (nv <= VSTAGE = 64); per edge the arithmetic of closest_point_normal, the nearest edge by a wave minimum with
+            // the first edge winning ties (the sequential scan keeps the first strict minimum), inside = parity of the
+            // crossing hits.  A zero-length edge or x == c is degenerate geometry: eta = NaN, the step reports DEGENERATE.
+#pragma clang fp contract(off)
+            const bool eon = lane < nv;
+            const int ia = eon ? lane : 0, ib = (ia + 1 == nv) ? 0 : ia + 1, ip = (ia == 0) ? nv - 1 : ia - 1;
+            const EdgeCp ec = edge_closest(ring[2 * ip], ring[2 * ip + 1], ring[2 * ia], ring[2 * ia + 1], ring[2 * ib],
+                                           ring[2 * ib + 1], x0, y0);
+            double dmin = eon ? ec.d : INFINITY;
+            for (int m = 1; m < 64; m <<= 1) dmin = fmin(dmin, __shfl_xor(dmin, m, 64));
+            const int sel = __ffsll((long long)__ballot(eon && ec.d == dmin)) - 1;      // >= 0: lane 0 is always an edge
+            const double ccx = __shfl(ec.qx, sel, 64), ccy = __shfl(ec.qy, sel, 64);
+            const bool inside = (__popcll(__ballot(eon && ec.hit)) & 1) != 0;
+            bool degen = __any(eon && ec.degen);
+            double nx = x0 - ccx, ny = y0 - ccy;
+            const double nn = sqrt(nx * nx + ny * ny);
+            if (!(nn > 0.0)) degen = true;
+            nx = nx / nn; ny = ny / nn;
+            if (inside) { nx = -nx; ny = -ny; }
+            if (lane == 0) {
+              double* o = oce + (long)n_out * 4;
+              o[0] = ccx; o[1] = ccy; o[2] = degen ? NAN : nx; o[3] = degen ? NAN : ny;
+            }
+          }
           ++n_out;
         }
       }
@@ -478,15 +629,15 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
 
 }  // namespace
 
-extern "C" int lipmpc_lidar_sense_batch(int device, int64_t B, int32_t resolution, int32_t n_env, int32_t v_env,
-                                        int32_t env_shared, double lidar_range, double eps, int32_t min_samples,
-                                        int32_t n_obs_max, int32_t v_max, const double* state, const double* env_xy,
-                                        const int32_t* env_nv, const double* ray_table, const double* noise,
-                                        double* obs_xy, int32_t* obs_nv, int32_t* n_inferred, int32_t* overflow,
-                                        double* hits, int32_t* labels, void* hip_stream) {
+static int lidar_launch(int device, int64_t B, int32_t resolution, int32_t n_env, int32_t v_env, int32_t env_shared,
+                        double lidar_range, double eps, int32_t min_samples, int32_t n_obs_max, int32_t v_max,
+                        const double* state, const double* env_xy, const int32_t* env_nv, const double* ray_table,
+                        const double* noise, double* obs_xy, int32_t* obs_nv, double* c_eta, int32_t* n_inferred,
+                        int32_t* overflow, double* hits, int32_t* labels, void* hip_stream) {
   if (B < 0 || resolution < 1 || resolution > RMAX || n_env < 0 || v_env < 1 || n_obs_max < 1 || v_max < 3 || v_max > VSTAGE) return LIPMPC_E_ARG;
   if (B == 0) return LIPMPC_OK;
-  if (!state || !ray_table || !obs_xy || !obs_nv || !n_inferred || !overflow || (n_env > 0 && (!env_xy || !env_nv)))
+  if (!state || !ray_table || !n_inferred || !overflow || (n_env > 0 && (!env_xy || !env_nv)) || (!obs_xy != !obs_nv) ||
+      (!obs_xy && !c_eta))
     return LIPMPC_E_ARG;
   if (hipSetDevice(device) != hipSuccess) return LIPMPC_E_HIP;
 #ifdef LIPMPC_LIDAR_PHASES
@@ -498,6 +649,28 @@ extern "C" int lipmpc_lidar_sense_batch(int device, int64_t B, int32_t resolutio
 #endif
   hipLaunchKernelGGL(lidar_sense_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)hip_stream, (long)B, resolution, n_env,
                      v_env, (long)(env_shared ? 0 : 1), lidar_range, eps, min_samples, n_obs_max, v_max, state, env_xy, env_nv,
-                     ray_table, noise, obs_xy, obs_nv, n_inferred, overflow, hits, labels, dbg_stop);
+                     ray_table, noise, obs_xy, obs_nv, c_eta, n_inferred, overflow, hits, labels, dbg_stop);
   return hipGetLastError() == hipSuccess ? LIPMPC_OK : LIPMPC_E_HIP;
+}
+
+extern "C" int lipmpc_lidar_sense_batch(int device, int64_t B, int32_t resolution, int32_t n_env, int32_t v_env,
+                                        int32_t env_shared, double lidar_range, double eps, int32_t min_samples,
+                                        int32_t n_obs_max, int32_t v_max, const double* state, const double* env_xy,
+                                        const int32_t* env_nv, const double* ray_table, const double* noise,
+                                        double* obs_xy, int32_t* obs_nv, int32_t* n_inferred, int32_t* overflow,
+                                        double* hits, int32_t* labels, void* hip_stream) {
+  if (!obs_xy || !obs_nv) return LIPMPC_E_ARG;
+  return lidar_launch(device, B, resolution, n_env, v_env, env_shared, lidar_range, eps, min_samples, n_obs_max, v_max, state,
+                      env_xy, env_nv, ray_table, noise, obs_xy, obs_nv, nullptr, n_inferred, overflow, hits, labels, hip_stream);
+}
+
+extern "C" int lipmpc_lidar_c_eta_batch(int device, int64_t B, int32_t resolution, int32_t n_env, int32_t v_env,
+                                        int32_t env_shared, double lidar_range, double eps, int32_t min_samples,
+                                        int32_t n_obs_max, int32_t v_max, const double* state, const double* env_xy,
+                                        const int32_t* env_nv, const double* ray_table, const double* noise,
+                                        double* c_eta, int32_t* n_inferred, int32_t* overflow, double* obs_xy,
+                                        int32_t* obs_nv, double* hits, int32_t* labels, void* hip_stream) {
+  if (!c_eta) return LIPMPC_E_ARG;
+  return lidar_launch(device, B, resolution, n_env, v_env, env_shared, lidar_range, eps, min_samples, n_obs_max, v_max, state,
+                      env_xy, env_nv, ray_table, noise, obs_xy, obs_nv, c_eta, n_inferred, overflow, hits, labels, hip_stream);
 }

@@ -45,25 +45,45 @@ class LidarSensor:
         self.env_nv = torch.as_tensor(nv, device=self.device)
         self.table = torch.as_tensor(ray_table(self.resolution), device=self.device)
 
-    def alloc_outputs(self, B, with_debug=False):
+    def alloc_outputs(self, B, with_debug=False, rings=True, c_eta=False):
+        """Output buffers of ``sense``: rings (obs_xy, obs_nv) and / or the assembled half-spaces c_eta [B,n_obs_max,4]."""
         dev = self.device
-        out = dict(obs_xy=torch.zeros((B, self.n_obs_max, self.v_max, 2), dtype=torch.float64, device=dev),
-                   obs_nv=torch.zeros((B, self.n_obs_max), dtype=torch.int32, device=dev),
-                   n_inferred=torch.zeros((B,), dtype=torch.int32, device=dev),
+        out = dict(n_inferred=torch.zeros((B,), dtype=torch.int32, device=dev),
                    overflow=torch.zeros((B,), dtype=torch.int32, device=dev))
+        if rings:
+            out["obs_xy"] = torch.zeros((B, self.n_obs_max, self.v_max, 2), dtype=torch.float64, device=dev)
+            out["obs_nv"] = torch.zeros((B, self.n_obs_max), dtype=torch.int32, device=dev)
+        if c_eta:
+            out["c_eta"] = torch.zeros((B, self.n_obs_max, 4), dtype=torch.float64, device=dev)
         if with_debug:
             out["hits"] = torch.empty((B, self.resolution, 2), dtype=torch.float64, device=dev)
             out["labels"] = torch.empty((B, self.resolution), dtype=torch.int32, device=dev)
         return out
 
-    def sense(self, state, noise=None, with_debug=False, out=None, env_xy=None, env_nv=None):
-        """state [B,5] device tensor; noise [B,resolution,2] or None -> dict(obs_xy, obs_nv, n_inferred, overflow[, hits, labels]).
+    def sense(self, state, noise=None, with_debug=False, out=None, env_xy=None, env_nv=None, c_eta=False, rings=True):
+        """state [B,5] device tensor; noise [B,resolution,2] or None -> dict(n_inferred, overflow[, obs_xy, obs_nv][, c_eta]
+        [, hits, labels]).  ``c_eta=True``: the constraint assembly runs in the same launch (lipmpc_lidar_c_eta_batch) and
+        the dict carries c_eta [B,n_obs_max,4] = (c, eta) of every inferred hull at the robot's CoM -- what
+        ``BatchedLipMpc.plan_step_batch_c_eta`` solves against; with ``rings=False`` the hulls never leave the kernel.
         Vertex slots beyond obs_nv keep whatever an earlier call left there when ``out`` is reused.
         ``env_xy`` [B,n_env,v_env,2] / ``env_nv`` [B,n_env] (device tensors): one true map PER ROBOT instead of the
         sensor's shared map (env_shared = 0 of the C ABI)."""
         B, dev = state.shape[0], self.device
         if out is None:
-            out = self.alloc_outputs(B, with_debug)
+            out = self.alloc_outputs(B, with_debug, rings=rings or not c_eta, c_eta=c_eta)
+        want_ce = "c_eta" in out
+        for name, shape, dt in (("obs_xy", (B, self.n_obs_max, self.v_max, 2), torch.float64), ("obs_nv", (B, self.n_obs_max), torch.int32),
+                                ("c_eta", (B, self.n_obs_max, 4), torch.float64), ("n_inferred", (B,), torch.int32),
+                                ("overflow", (B,), torch.int32), ("hits", (B, self.resolution, 2), torch.float64),
+                                ("labels", (B, self.resolution), torch.int32)):
+            t = out.get(name)
+            if t is not None and (tuple(t.shape) != shape or t.dtype != dt or t.device != dev or not t.is_contiguous()):
+                raise ValueError(f"out['{name}']: expected contiguous {dt} {shape} on {dev}")
+        if (state.dtype != torch.float64 or state.dim() != 2 or state.shape[1] != 5 or state.device != dev or not state.is_contiguous()):
+            raise ValueError(f"state: expected contiguous float64 [B,5] on {dev}")
+        if noise is not None and (tuple(noise.shape) != (B, self.resolution, 2) or noise.dtype != torch.float64
+                                  or noise.device != dev or not noise.is_contiguous()):
+            raise ValueError(f"noise: expected contiguous float64 {(B, self.resolution, 2)} on {dev}")
         stream = torch.cuda.current_stream(dev).cuda_stream
         n_env, v_env, shared, exy, env = self.n_env, self.v_env, 1, self.env_xy, self.env_nv
         if env_xy is not None:
@@ -73,12 +93,18 @@ class LidarSensor:
                     or env_xy.device != dev or env_nv.device != dev):
                 raise ValueError("per-robot maps: env_xy [B,n_env,v_env,2] float64, env_nv [B,n_env] int32, contiguous, on the sensor's device")
             n_env, v_env, shared, exy, env = int(env_xy.shape[1]), int(env_xy.shape[2]), 0, env_xy, env_nv
-        rc = self.lib.lipmpc_lidar_sense_batch(
-            self.device_index, B, self.resolution, n_env, v_env, shared, self.lidar_range, DBSCAN_EPS,
-            DBSCAN_MIN_SAMPLES, self.n_obs_max, self.v_max, _ptr(state), _ptr(exy), _ptr(env),
-            _ptr(self.table), _ptr(noise), _ptr(out["obs_xy"]), _ptr(out["obs_nv"]), _ptr(out["n_inferred"]),
-            _ptr(out["overflow"]), _ptr(out.get("hits")), _ptr(out.get("labels")), C.c_void_p(stream))
-        _lib.check(rc, "lipmpc_lidar_sense_batch")
+        head = (self.device_index, B, self.resolution, n_env, v_env, shared, self.lidar_range, DBSCAN_EPS,
+                DBSCAN_MIN_SAMPLES, self.n_obs_max, self.v_max, _ptr(state), _ptr(exy), _ptr(env), _ptr(self.table), _ptr(noise))
+        if want_ce:
+            rc = self.lib.lipmpc_lidar_c_eta_batch(*head, _ptr(out["c_eta"]), _ptr(out["n_inferred"]), _ptr(out["overflow"]),
+                                                   _ptr(out.get("obs_xy")), _ptr(out.get("obs_nv")), _ptr(out.get("hits")),
+                                                   _ptr(out.get("labels")), C.c_void_p(stream))
+            _lib.check(rc, "lipmpc_lidar_c_eta_batch")
+        else:
+            rc = self.lib.lipmpc_lidar_sense_batch(*head, _ptr(out["obs_xy"]), _ptr(out["obs_nv"]), _ptr(out["n_inferred"]),
+                                                   _ptr(out["overflow"]), _ptr(out.get("hits")), _ptr(out.get("labels")),
+                                                   C.c_void_p(stream))
+            _lib.check(rc, "lipmpc_lidar_sense_batch")
         return out
 
 
@@ -101,13 +127,14 @@ class HumanoidMPCUnknownEnvironment(HumanoidMPC):
         self._gen = None if noise_seed is None else torch.Generator(device=self._sensor.device).manual_seed(int(noise_seed))
         self.list_inferred_obstacles = []
 
-    def _get_obstacle_rings(self, x_k: float, y_k: float):
+    def _sense(self, x_k: float, y_k: float):
+        """One scan at (x_k, y_k): (c_eta [n,4], rings) of the inferred obstacles, c / eta assembled in the scan's launch."""
         dev = self._sensor.device
         st = torch.tensor([[x_k, 0.0, y_k, 0.0, 0.0]], dtype=torch.float64, device=dev)
         noise = None
         if self._gen is not None:
             noise = NOISE_STD * torch.randn((1, self.lidar_resolution, 2), dtype=torch.float64, device=dev, generator=self._gen)
-        out = self._sensor.sense(st, noise)
+        out = self._sensor.sense(st, noise, c_eta=True)
         torch.cuda.synchronize(dev)
         if int(out["overflow"][0]):
             # more clusters / longer hulls than the default slots: scan again (same noise) into the largest layout the
@@ -116,7 +143,7 @@ class HumanoidMPCUnknownEnvironment(HumanoidMPC):
             if self._big_sensor is None:
                 self._big_sensor = LidarSensor(self._env, self.lidar_range, self.lidar_resolution, n_obs_max=50, v_max=32,
                                                device=self._device)
-            out = self._big_sensor.sense(st, noise)
+            out = self._big_sensor.sense(st, noise, c_eta=True)
             torch.cuda.synchronize(dev)
             if int(out["overflow"][0]):
                 raise RuntimeError("LiDAR scan inferred more obstacles / hull vertices than the solver holds (50 x 32)")
@@ -125,7 +152,18 @@ class HumanoidMPCUnknownEnvironment(HumanoidMPC):
         xy = out["obs_xy"][0].cpu().numpy()
         rings = [xy[j, :nv[j]].copy() for j in range(n)]
         self.list_inferred_obstacles.append(rings)
-        return rings
+        return out["c_eta"][0, :n].cpu().numpy(), rings
+
+    def _get_list_c_and_eta(self, x_k: float, y_k: float):
+        """The hook the reference's variant overrides (HumanoidMPCUnknownEnvironment.py:30-68): scan, cluster, hulls,
+        closest point and normal per hull -- one launch (lipmpc_lidar_c_eta_batch); the step is then solved against
+        these half-spaces through lipmpc_plan_step_batch_c_eta."""
+        ce, _ = self._sense(x_k, y_k)
+        return [r[:2].reshape(2, 1) for r in ce], [r[2:].reshape(2, 1) for r in ce]
+
+    def _get_obstacle_rings(self, x_k: float, y_k: float):
+        """The inferred obstacles as rings (one scan), for callers that want the polygons."""
+        return self._sense(x_k, y_k)[1]
 
 
 class UnknownEnvFleet:
@@ -163,7 +201,7 @@ class UnknownEnvFleet:
                   n_overflow=torch.zeros((B,), dtype=torch.int32, device=dev),
                   sample=torch.zeros((1,), dtype=torch.int32, device=dev),
                   X_pred=X, U_pred=torch.zeros((B, k_max, 3), dtype=torch.float64, device=dev))
-        sen = sn.alloc_outputs(B)
+        sen = sn.alloc_outputs(B, rings=False, c_eta=True)       # hulls stay in the scan kernel: only (c, eta) rows reach HBM
         out = sv.alloc_outputs(B)
         nbuf = None if noise is None else torch.zeros((B, sn.resolution, 2), dtype=torch.float64, device=dev)
         gen = torch.Generator(device=dev).manual_seed(int(noise_seed)) if isinstance(noise, str) else None
@@ -172,7 +210,7 @@ class UnknownEnvFleet:
             # HumanoidMpc.py:387/:417 sense + solve; :392 stop rule, :419-429 failed solve ends the run, :432-447 advance
             # and the trajectory row: one bookkeeping launch (lipmpc_fleet_update_batch)
             sn.sense(fl["state"], nbuf, out=sen)
-            sv.plan_step_batch(fl["state"], goal, fl["first_foot"], sen["obs_xy"], sen["obs_nv"], delta, out=out)
+            sv.plan_step_batch_c_eta(fl["state"], goal, fl["first_foot"], sen["c_eta"], delta, out=out)
             sv.fleet_update(fl, out, overflow=sen["overflow"], stop_obj=stop_obj)
 
         def fill_noise(k):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LIPMPC_ABI_VERSION 2   /* 2: + lipmpc_plan_step_batch_c_eta, LIPMPC_STATUS_SENSOR_OVERFLOW */
+#define LIPMPC_ABI_VERSION 3   /* 2: + lipmpc_plan_step_batch_c_eta, LIPMPC_STATUS_SENSOR_OVERFLOW; 3: + lipmpc_lidar_c_eta_batch */
 
 /* per-problem status written to status[b] */
 #define LIPMPC_STATUS_SOLVED       0  /* exact optimum, KKT-certified active set */
@@ -127,8 +127,9 @@ int lipmpc_plan_step_batch(lipmpc_handle* h, int64_t B,
  * hooks HumanoidMPC._get_list_c_and_eta(x_k, y_k) -> (list_c, list_eta) (HumanoidMpc.py:296-319; overridden by
  * HumanoidMPCUnknownEnvironment.py:30-68) and _compute_single_lcbf(x, eta, c) (HumanoidMpc.py:252-261; overridden by
  * HumanoidMPCCustomLCBF.py:30-31) as data.  Row j of every stage k is  eta_j . (p_k - c_j) - delta >= 0  with
- *  c_eta_in [B,n_obs_max,4] (c_x, c_y, eta_x, eta_y); eta need not be a unit vector; eta = (0,0) marks an empty slot.
- * Nothing of the geometry front end runs (no DEGENERATE status); the constant k = 0 row is still checked against k0_tol.
+ *  c_eta_in [B,n_obs_max,4] (c_x, c_y, eta_x, eta_y); eta need not be a unit vector; eta = (0,0) marks an empty slot,
+ *  a NaN in eta marks degenerate geometry met by whoever produced the row (status DEGENERATE, as the ring front end gives).
+ * Nothing of the geometry front end runs; the constant k = 0 row is still checked against k0_tol.
  * Outputs as lipmpc_plan_step_batch (without c_eta). */
 int lipmpc_plan_step_batch_c_eta(lipmpc_handle* h, int64_t B,
                                  const double* state, const double* goal, const int8_t* first_foot,
@@ -202,6 +203,25 @@ int lipmpc_lidar_sense_batch(int device, int64_t B, int32_t resolution, int32_t 
                              const int32_t* env_nv, const double* ray_table, const double* noise,
                              double* obs_xy, int32_t* obs_nv, int32_t* n_inferred, int32_t* overflow,
                              double* hits, int32_t* labels, void* hip_stream);
+
+/* Unknown-environment CONSTRAINT ASSEMBLY in one launch (BASELINE config 5: "LiDAR point cloud -> convex-hull obstacle
+ * rebuild fused into the constraint-assembly kernel"): everything HumanoidMPCUnknownEnvironment._get_list_c_and_eta does
+ * (HumanoidMPCUnknownEnvironment.py:30-68) -- range_finder() as in lipmpc_lidar_sense_batch, then for every inferred
+ * hull the closest point c and the unit normal eta at the robot's CoM with the inside flip (:54-62 ->
+ * ObstaclesUtils.py:60-109) -- with the hulls never leaving LDS.  The (c, eta) rows are the LDCBF half-spaces
+ * lipmpc_plan_step_batch_c_eta solves against; they are bit-identical to what lipmpc_plan_step_batch derives from the
+ * rings lipmpc_lidar_sense_batch writes.
+ *  inputs as lipmpc_lidar_sense_batch
+ *  c_eta [B,n_obs_max,4] (c_x, c_y, eta_x, eta_y) per inferred obstacle, cluster order; empty slots all zero;
+ *        eta = NaN where the geometry is degenerate (CoM on the hull boundary, zero-length hull edge)
+ *  n_inferred [B], overflow [B] as lipmpc_lidar_sense_batch
+ *  obs_xy / obs_nv: the rings as well, or both NULL;  hits, labels: or NULL */
+int lipmpc_lidar_c_eta_batch(int device, int64_t B, int32_t resolution, int32_t n_env, int32_t v_env,
+                             int32_t env_shared, double lidar_range, double eps, int32_t min_samples,
+                             int32_t n_obs_max, int32_t v_max, const double* state, const double* env_xy,
+                             const int32_t* env_nv, const double* ray_table, const double* noise,
+                             double* c_eta, int32_t* n_inferred, int32_t* overflow, double* obs_xy,
+                             int32_t* obs_nv, double* hits, int32_t* labels, void* hip_stream);
 
 const char* lipmpc_strerror(int code);
 int lipmpc_version(void);

@@ -299,3 +299,72 @@ def test_gpu_more_clusters_than_slots(golden_dir):
     torch.cuda.synchronize()
     assert int(r["n_steps"][0]) == 0 and int(r["last_status"][0]) == lipmpc.STATUS_SENSOR_OVERFLOW and int(r["overflow"][0]) == 1
     assert int(r["n_steps"][1]) == 4 and int(r["overflow"][1]) == 0
+
+
+@pytest.mark.gpu
+def test_gpu_constraint_assembly_fused_into_the_scan(golden_dir):
+    """lipmpc_lidar_c_eta_batch (scan -> clusters -> hulls -> closest point / normal in ONE launch, hulls in LDS) against
+    (a) the oracle chain lidar oracle -> closest_point_and_normal on the reference's golden scans and (b), for 4096
+    robots, the two-launch path: the (c, eta) rows are bit-identical to what the step kernel's front end derives from
+    the rings lipmpc_lidar_sense_batch writes, and so is everything the step solves from them."""
+    torch = pytest.importorskip("torch")
+    import lipmpc
+    import lipmpc_oracle as O
+    d = np.load(os.path.join(golden_dir, "lidar_golden.npz"))
+    tab = L.ray_table()
+    worst = 0.0
+    for i in range(0, len(d["pos"]), 2):
+        pos, rings, rng = _case(d, i)
+        sensor = lipmpc.LidarSensor(rings, lidar_range=rng, resolution=360, n_obs_max=12, v_max=40)
+        st = torch.tensor([[pos[0], 0.0, pos[1], 0.0, 0.0]], dtype=torch.float64, device="cuda")
+        out = sensor.sense(st, torch.as_tensor(d["noise"][i][None], device="cuda"), c_eta=True)
+        torch.cuda.synchronize()
+        n = int(out["n_inferred"][0]); ce = out["c_eta"][0].cpu().numpy()
+        assert n == int((d["inf_nv"][i] > 0).sum()) and int(out["overflow"][0]) == 0
+        assert np.all(ce[n:] == 0.0)
+        for j in range(n):
+            ref_ring = d["inf_xy"][i][j][: d["inf_nv"][i][j]]                       # Qhull's ring, from the reference
+            c, eta, _, degen = O.closest_point_and_normal(np.array([pos[0], pos[1]]), ref_ring)
+            assert not degen
+            worst = max(worst, float(np.max(np.abs(ce[j, :2] - c))), float(np.max(np.abs(ce[j, 2:] - eta))))
+    assert worst < 1e-13, worst
+    # 4096 robots on one map: fused constraint assembly == rings -> front end of the step kernel, bit for bit
+    _, rings, _ = _case(d, 0)
+    B, N = 4096, 3
+    rng = np.random.default_rng(11)
+    pos = rng.uniform(-0.8, 5.8, (B, 2))
+    st = np.zeros((B, 5)); st[:, 0] = pos[:, 0]; st[:, 2] = pos[:, 1]; st[:, 4] = rng.uniform(-1, 1, B)
+    d_st = torch.as_tensor(st, device="cuda")
+    noise = torch.as_tensor(0.01 * rng.standard_normal((B, 360, 2)), device="cuda")
+    sensor = lipmpc.LidarSensor(rings, lidar_range=1.5, n_obs_max=12, v_max=32)
+    two = sensor.sense(d_st, noise)
+    one = sensor.sense(d_st, noise, c_eta=True)
+    lean = sensor.sense(d_st, noise, c_eta=True, rings=False)                       # hulls never leave the kernel
+    sv = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=12, v_max=32))
+    goal = torch.tensor([[5.0, 5.0]], dtype=torch.float64, device="cuda").repeat(B, 1).contiguous()
+    foot = torch.ones((B,), dtype=torch.int8, device="cuda")
+    delta = torch.as_tensor(rng.choice([0.0, 0.05], B), device="cuda")
+    ref = sv.plan_step_batch(d_st, goal, foot, two["obs_xy"], two["obs_nv"], delta, with_c_eta=True)
+    got = sv.plan_step_batch_c_eta(d_st, goal, foot, lean["c_eta"], delta)
+    torch.cuda.synchronize()
+    assert "obs_xy" not in lean
+    for k in ("n_inferred", "overflow", "obs_nv"):
+        assert torch.equal(one[k], two[k]), k
+    assert torch.equal(one["c_eta"], lean["c_eta"]) and torch.equal(one["n_inferred"], lean["n_inferred"])
+    has = (two["obs_nv"] > 0)
+    assert torch.equal(one["obs_xy"][has], two["obs_xy"][has])
+    assert torch.equal(torch.nan_to_num(one["c_eta"][has], nan=7.0), torch.nan_to_num(ref["c_eta"][has], nan=7.0))
+    assert int(has.sum()) > 2 * B and not bool(torch.any(one["c_eta"][~has] != 0.0))
+    st_ref, st_got = ref["status"].cpu().numpy(), got["status"].cpu().numpy()
+    assert np.array_equal(st_ref, st_got)
+    for k in ("iters", "active", "theta", "omega"):
+        assert torch.equal(ref[k], got[k]), k
+    ok = torch.as_tensor((st_ref == 0) | (st_ref == 4), device="cuda")
+    for k in ("U", "X", "obj"):
+        assert torch.equal(ref[k][ok], got[k][ok]), k
+    assert int(ok.sum()) > 0.6 * B
+    # a NaN normal in the rows (degenerate geometry met by the producer) is reported as DEGENERATE, like the ring front end
+    ce = lean["c_eta"][:4].clone(); ce[1, 0, 2] = float("nan")
+    r = sv.plan_step_batch_c_eta(d_st[:4].contiguous(), goal[:4].contiguous(), foot[:4].contiguous(), ce.contiguous())
+    torch.cuda.synchronize()
+    assert int(r["status"][1]) == lipmpc.STATUS_DEGENERATE

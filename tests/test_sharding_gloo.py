@@ -86,3 +86,27 @@ def test_two_rank_gloo_sharded_batch():
     for r in res:
         assert r[5] == 1.5 and r[6] == B and r[7] == int(np.sum(full["status"] == 0))
         assert r[8].shape == (2, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_two_rank_bench_with_the_hip_solver():
+    """bench.py's N > 1 path with the HIP solver on both ranks: two processes launched the way the driver launches them
+    (torch.distributed.run), each solving its contiguous shard of ONE batch on the device; on a one-GPU box both ranks
+    share device 0 and gloo stands in for RCCL (LIPMPC_BENCH_REHEARSE=1).  Checks the whole-job bookkeeping of the JSON
+    line: shard sizes, strong scaling, counters gathered over both ranks, value = problems x steps / max time."""
+    import json
+    import subprocess
+    env = dict(os.environ, LIPMPC_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--total-batch", "3000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "strong"
+    assert d["config"]["total_batch"] == 3000 and d["config"]["batch_rank0"] == 1500
+    assert abs(d["value"] - 3000 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
+    assert d["solver"]["solved_frac"] > 0.95 and "REHEARSAL" in d["data"]

@@ -1,13 +1,23 @@
+"""Dev tool: LiDAR kernel time up to a phase (library built with -DLIPMPC_LIDAR_PHASES, LIPMPC_LIDAR_STOP=1..5 in the
+environment; 1 rays, 2 neighbour rows, 4 components, 5 cluster roots, 3 labels; 0 = whole kernel) for B robots (argv[1])."""
 import sys, os, numpy as np, torch
-ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import lipmpc
-d=np.load(os.path.join(ROOT,'tests/golden/lidar_golden.npz'))
-rings=[d["env"][0][j][:d["env_nv"][0][j]] for j in range(20)]
-B=4096; rng=np.random.default_rng(0); pos=rng.uniform(-0.8,5.8,(B,2)); st=np.zeros((B,5)); st[:,0]=pos[:,0]; st[:,2]=pos[:,1]
-d_st=torch.as_tensor(st,device="cuda"); sensor=lipmpc.LidarSensor(rings,lidar_range=1.5,n_obs_max=12,v_max=32)
-noise=0.01*torch.randn((B,360,2),dtype=torch.float64,device="cuda")
-for _ in range(3): sensor.sense(d_st,noise)
-torch.cuda.synchronize(); e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+from importlib import import_module
+synth = import_module("humanoid-navigation-using-mpc-ldcbf_amd.synth")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+dev = torch.device("cuda", 0)
+exy, env = synth.synthetic_fields(1, 20, -1.0, 6.0, (-5.0, -5.0), (50.0, 50.0), seed=9, delta=0.6)
+rings = [exy[0, j, : env[0, j]] for j in range(20) if env[0, j] > 0]
+sensor = lipmpc.LidarSensor(rings, lidar_range=1.5, resolution=360, n_obs_max=12, v_max=32, device=0)
+gen = torch.Generator(device=dev).manual_seed(3)
+pos = torch.rand((B, 2), dtype=torch.float64, device=dev, generator=gen) * 7.0 - 1.0
+state = torch.zeros((B, 5), dtype=torch.float64, device=dev); state[:, 0] = pos[:, 0]; state[:, 2] = pos[:, 1]
+noise = 0.01 * torch.randn((B, 360, 2), dtype=torch.float64, device=dev, generator=gen)
+sen = sensor.alloc_outputs(B)
+for _ in range(3): sensor.sense(state, noise, out=sen)
+torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(10): sensor.sense(d_st,noise)
-e1.record(); torch.cuda.synchronize(); print('stop',os.environ.get('LIPMPC_LIDAR_STOP','0'),'%.3f ms'%(e0.elapsed_time(e1)/10))
+for _ in range(20): sensor.sense(state, noise, out=sen)
+e1.record(); torch.cuda.synchronize()
+print('B', B, 'stop', os.environ.get('LIPMPC_LIDAR_STOP', '0'), '%.1f us' % (e0.elapsed_time(e1) / 20 * 1e3))
