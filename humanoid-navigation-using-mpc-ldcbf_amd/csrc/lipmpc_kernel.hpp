@@ -281,7 +281,8 @@ struct RowFlags {
 // contraction off so that comparisons see the same roundings as the CPU oracle
 // ------------------------------------------------------------------------------------------
 struct ClosestPoint { double cx, cy, ex, ey; int degenerate; };      // returned in registers: no stack traffic for the call
-__device__ __noinline__ ClosestPoint closest_point_normal(const double* __restrict__ ring, int nv, double px, double py) {
+template <class RingPtr>
+__device__ __forceinline__ ClosestPoint closest_point_impl(RingPtr ring, int nv, double px, double py) {
 #pragma clang fp contract(off)
   double best = INFINITY;
   ClosestPoint r;
@@ -322,6 +323,10 @@ __device__ __noinline__ ClosestPoint closest_point_normal(const double* __restri
   if (inside) { nx = -nx; ny = -ny; }
   r.ex = nx; r.ey = ny;
   return r;
+}
+// rings in global memory: out of line (one copy per kernel, result in registers)
+__device__ __noinline__ ClosestPoint closest_point_normal(const double* __restrict__ ring, int nv, double px, double py) {
+  return closest_point_impl(ring, nv, px, py);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -386,6 +391,11 @@ __device__ __forceinline__ StepOut step_body(
   constexpr bool FUSED = (G == 16);    // one-instruction substitution / elimination steps (fmac_bcast)
 #endif
 
+  // a problem's obstacle rings staged in LDS by one coalesced sweep of the group when they fit (n_obs x v_max vertices
+  // <= RING_CAP: the 10 x 5 of BASELINE config 2 do): the edge walk of the closest-point step then reads LDS instead
+  // of paying one global-memory latency per edge
+  constexpr int RING_CAP = (G == 16) ? 64 : 256;
+  __shared__ double lds_ring[GPW][MAXOBS > 0 ? RING_CAP : 1][2];
   __shared__ double lds_obs[GPW][MAXOBS > 0 ? MAXOBS : 1][4];   // eta_x, eta_y, b = eta.c + delta, h0
   __shared__ double lds_P[GPW][NMAX][2][2];                     // P_b blocks of the velocity part of K
   __shared__ unsigned long long lds_act[GPW][MAXWORDS];
@@ -424,9 +434,12 @@ __device__ __forceinline__ StepOut step_body(
       th = thn;
     }
   }
-  double cr, sr, cv, sv;
-  sincos(th_r, &sr, &cr);
-  sincos(th_v, &sv, &cv);
+  // R(theta_a) and W(theta_{a+1}): one sincos per lane (the c = 0 lane of a stage takes theta_a, its partner
+  // theta_{a+1}), exchanged inside the stage
+  double s_own, c_own;
+  sincos(c ? th_v : th_r, &s_own, &c_own);
+  const double s_oth = gxor<G, 1>(s_own), c_oth = gxor<G, 1>(c_own);
+  const double sr = c ? s_oth : s_own, cr = c ? c_oth : c_own, sv = c ? s_own : s_oth, cv = c ? c_own : c_oth;
   const double foot_r = (a & 1) ? -foot0 : foot0;      // s_v[a]
   const double foot_v = -foot_r;                        // s_v[a+1]
   // Row vectors in OWN / PARTNER form: lane (a, c) holds coordinate c of its stage ("own") and gets the other one from
@@ -442,6 +455,12 @@ __device__ __forceinline__ StepOut step_body(
 
   // ---- obstacles: c_j, eta_j at the current CoM (HumanoidMpc.py:296-319) ----------------------
   if (lane == 0) lds_flag[grp] = 0;
+  const bool staged = MAXOBS > 0 && !c_eta_in && P.n_obs * P.nvert_max <= RING_CAP;     // wave-uniform
+  if (staged) {
+    const double* src = obs_xy + pb * (long)P.n_obs * P.nvert_max * 2;
+    double* dst = &lds_ring[grp][0][0];
+    for (int v = lane; v < P.n_obs * P.nvert_max * 2; v += G) dst[v] = src[v];
+  }
   wave_sync();
   if (MAXOBS > 0) {
     for (int j = lane; j < MAXOBS; j += G) {
@@ -461,7 +480,8 @@ __device__ __forceinline__ StepOut step_body(
         const int nv = obs_nv[oidx];
         there = nv > 0;
         if (there) {
-          const ClosestPoint cp = closest_point_normal(obs_xy + oidx * P.nvert_max * 2, nv, p0x, p0y);
+          const ClosestPoint cp = staged ? closest_point_impl(&lds_ring[grp][j * P.nvert_max][0], nv, p0x, p0y)
+                                         : closest_point_normal(obs_xy + oidx * P.nvert_max * 2, nv, p0x, p0y);
           cx = cp.cx; cy = cp.cy; ex = cp.ex; ey = cp.ey;
           degen = cp.degenerate != 0;
         }
@@ -885,9 +905,11 @@ __device__ __forceinline__ StepOut step_body(
         const double ramp = fmin(1.0, fmax(0.0, (mu * __builtin_amdgcn_rcp(mu_prev) - IPM_SLOW_RATIO) * (1.0 / (1.0 - IPM_SLOW_RATIO))));
         if (lane == 0) { lds_mu[grp][0] = mu; lds_mu[grp][1] = (it >= IPM_SLOW_FROM) ? IPM_SLOW_SIGMA * ramp : 0.0; }
       }
-      const double rpmax = gmax<G>(rpmax_l);
-      const double zq = gmax<G>(fmax(zmax_l * (1.0 / IPM_Z_DIVERGE), fabs(q) * 1e-300));   // >= 1: diverged
-      const bool bad = !(zq < 1.0);
+      // largest primal residual and the divergence test (z or |q| out of range, NaN included) in ONE group reduction: a
+      // lane that sees divergence contributes +inf
+      const double zq_l = fmax(zmax_l * (1.0 / IPM_Z_DIVERGE), fabs(q) * 1e-300);        // >= 1: diverged
+      const double rpmax = gmax<G>(!(zq_l < 1.0) ? INFINITY : rpmax_l);
+      const bool bad = !(rpmax < INFINITY);
       if (rpmax <= P.tol && mu <= P.tol) { status = LIPMPC_STATUS_SOLVED; done = true; iters = it; }
       else if (it == P.max_iter) { done = true; iters = it; }
       else if (bad) { status = LIPMPC_STATUS_INFEASIBLE; done = true; iters = it; }

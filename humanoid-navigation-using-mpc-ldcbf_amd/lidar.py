@@ -183,67 +183,87 @@ class UnknownEnvFleet:
                                     self.sensor.device_index)
         self.device = self.sensor.device
 
+    def _plan_for(self, B, k_max, noise_mode, have_delta, stop_obj, use_graph):
+        """Buffers (and, once captured, the HIP graph of one sample) of a run shape; kept across ``run`` calls, so a
+        second run of the same shape replays the graph it already has."""
+        key = (B, k_max, noise_mode, have_delta, float(stop_obj), bool(use_graph))
+        pl = getattr(self, "_plan", None)
+        if pl is not None and pl["key"] == key:
+            return pl
+        dev, sn, sv = self.device, self.sensor, self.solver
+        f64 = dict(dtype=torch.float64, device=dev)
+        fl = dict(state=torch.zeros((B, 5), **f64), first_foot=torch.ones((B,), dtype=torch.int8, device=dev),
+                  walking=torch.ones((B,), dtype=torch.int8, device=dev), last_obj=torch.zeros((B,), **f64),
+                  n_steps=torch.zeros((B,), dtype=torch.int32, device=dev),
+                  last_status=torch.zeros((B,), dtype=torch.int32, device=dev),
+                  n_overflow=torch.zeros((B,), dtype=torch.int32, device=dev),
+                  sample=torch.zeros((1,), dtype=torch.int32, device=dev),
+                  X_pred=torch.zeros((B, k_max + 1, 5), **f64), U_pred=torch.zeros((B, k_max, 3), **f64))
+        pl = dict(key=key, fl=fl, goal=torch.zeros((B, 2), **f64), delta=torch.zeros((B,), **f64) if have_delta else None,
+                  sen=sn.alloc_outputs(B, rings=False, c_eta=True),      # hulls stay in the scan kernel: only (c, eta) rows reach HBM
+                  out=sv.alloc_outputs(B), nbuf=None if noise_mode == "none" else torch.zeros((B, sn.resolution, 2), **f64),
+                  gen=torch.Generator(device=dev) if noise_mode == "seeded" else None, graph=None)
+        self._plan = pl
+        return pl
+
     def run(self, state0, goal, first_foot, k_max, noise="seeded", noise_seed=0, delta=None, stop_obj=0.05,
             use_graph=True):
         """state0 [B,5], goal [B,2], first_foot [B] int8.  noise: "seeded" (N(0, 0.01) per reading from a generator
         seeded with noise_seed), None (noiseless) or a tensor [k_max,B,resolution,2].  Returns dict(X_pred
         [B,k_max+1,5], U_pred [B,k_max,3], n_steps [B] solved samples, last_status [B] (STATUS_SENSOR_OVERFLOW = 5: the
-        robot was stopped because a scan's clusters did not fit the obstacle slots), overflow [B] number of such scans)."""
+        robot was stopped because a scan's clusters did not fit the obstacle slots), overflow [B] number of such scans).
+        One sample = noise draw (seeded mode), scan + constraint assembly, step solve, fleet update; with ``use_graph``
+        it is captured once per run shape in a HIP graph (kept by the object) and replayed k_max times back to back.
+        The returned tensors are the object's buffers: the next ``run`` of the same shape overwrites them."""
         dev, sv, sn = self.device, self.solver, self.sensor
         B = state0.shape[0]
-        X = torch.zeros((B, k_max + 1, 5), dtype=torch.float64, device=dev)
-        X[:, 0] = state0
-        fl = dict(state=state0.clone(), first_foot=first_foot.clone(),
-                  walking=torch.ones((B,), dtype=torch.int8, device=dev),
-                  last_obj=torch.full((B,), float("inf"), dtype=torch.float64, device=dev),
-                  n_steps=torch.zeros((B,), dtype=torch.int32, device=dev),
-                  last_status=torch.zeros((B,), dtype=torch.int32, device=dev),
-                  n_overflow=torch.zeros((B,), dtype=torch.int32, device=dev),
-                  sample=torch.zeros((1,), dtype=torch.int32, device=dev),
-                  X_pred=X, U_pred=torch.zeros((B, k_max, 3), dtype=torch.float64, device=dev))
-        sen = sn.alloc_outputs(B, rings=False, c_eta=True)       # hulls stay in the scan kernel: only (c, eta) rows reach HBM
-        out = sv.alloc_outputs(B)
-        nbuf = None if noise is None else torch.zeros((B, sn.resolution, 2), dtype=torch.float64, device=dev)
-        gen = torch.Generator(device=dev).manual_seed(int(noise_seed)) if isinstance(noise, str) else None
+        mode = "none" if noise is None else ("seeded" if isinstance(noise, str) else "given")
+        pl = self._plan_for(B, int(k_max), mode, delta is not None, stop_obj, use_graph)
+        fl, sen, out, nbuf, gen = pl["fl"], pl["sen"], pl["out"], pl["nbuf"], pl["gen"]
+        pl["goal"].copy_(goal)
+        if delta is not None:
+            pl["delta"].copy_(delta)
+
+        def reset():
+            fl["state"].copy_(state0); fl["first_foot"].copy_(first_foot)
+            fl["walking"].fill_(1); fl["last_obj"].fill_(float("inf"))
+            for n in ("n_steps", "last_status", "n_overflow", "sample"):
+                fl[n].zero_()
+            fl["X_pred"].zero_(); fl["U_pred"].zero_(); fl["X_pred"][:, 0] = state0
+            if gen is not None:
+                gen.manual_seed(int(noise_seed))
 
         def sample():
             # HumanoidMpc.py:387/:417 sense + solve; :392 stop rule, :419-429 failed solve ends the run, :432-447 advance
             # and the trajectory row: one bookkeeping launch (lipmpc_fleet_update_batch)
-            sn.sense(fl["state"], nbuf, out=sen)
-            sv.plan_step_batch_c_eta(fl["state"], goal, fl["first_foot"], sen["c_eta"], delta, out=out)
-            sv.fleet_update(fl, out, overflow=sen["overflow"], stop_obj=stop_obj)
-
-        def fill_noise(k):
             if gen is not None:
                 nbuf.normal_(0.0, NOISE_STD, generator=gen)
-            elif nbuf is not None:
-                nbuf.copy_(noise[k])
+            sn.sense(fl["state"], nbuf, out=sen)
+            sv.plan_step_batch_c_eta(fl["state"], pl["goal"], fl["first_foot"], sen["c_eta"], pl["delta"], out=out)
+            sv.fleet_update(fl, out, overflow=sen["overflow"], stop_obj=stop_obj)
 
-        graph = None
-        if use_graph:
-            fill_noise(0)
-            names = ("state", "first_foot", "walking", "last_obj", "n_steps", "last_status", "n_overflow", "sample", "X_pred", "U_pred")
-            keep = {n: fl[n].clone() for n in names}
+        if use_graph and pl["graph"] is None:
+            reset()
+            if mode == "given":
+                nbuf.copy_(noise[0])
             side = torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 sample()                                     # warm-up outside capture (lazy initialisation)
             torch.cuda.current_stream(dev).wait_stream(side)
-            for n in names:
-                fl[n].copy_(keep[n])
-            if gen is not None:
-                gen.manual_seed(int(noise_seed))
             graph = torch.cuda.CUDAGraph()
+            if gen is not None:
+                graph.register_generator_state(gen)          # the draw is part of the graph: every replay advances the stream
             with torch.cuda.graph(graph):
                 sample()
-            for n in names:
-                fl[n].copy_(keep[n])
+            pl["graph"] = graph
+        reset()
         for k in range(k_max):
-            fill_noise(k)
-            if graph is not None:
-                graph.replay()
+            if mode == "given":
+                nbuf.copy_(noise[k])
+            if use_graph:
+                pl["graph"].replay()
             else:
                 sample()
         return dict(X_pred=fl["X_pred"], U_pred=fl["U_pred"], n_steps=fl["n_steps"], last_status=fl["last_status"],
                     overflow=fl["n_overflow"])
-

@@ -205,6 +205,17 @@ def test_gpu_unknown_environment_fleet_matches_class(golden_dir):
         assert r["n_steps"].min() >= 5 and r["overflow"].sum() == 0
     assert np.array_equal(res[False]["X_pred"], res[True]["X_pred"])
     assert np.array_equal(res[False]["n_steps"], res[True]["n_steps"])
+    # seeded noise drawn INSIDE the captured graph: a run is a function of its seed (the second run of a shape replays
+    # the graph the first one captured), and another seed walks another way
+    fleet = lipmpc.UnknownEnvFleet(rings, N_horizon=3, lidar_range=1.5)
+    runs = []
+    for seed in (3, 3, 4):
+        r = fleet.run(st0, goal, foot, K, noise_seed=seed)
+        torch.cuda.synchronize()
+        runs.append({k: v.cpu().numpy().copy() for k, v in r.items()})
+    assert np.array_equal(runs[0]["X_pred"], runs[1]["X_pred"]) and np.array_equal(runs[0]["n_steps"], runs[1]["n_steps"])
+    assert not np.array_equal(runs[0]["X_pred"], runs[2]["X_pred"])
+    assert runs[0]["n_steps"].min() >= 5
 
 
 @pytest.mark.gpu
