@@ -178,6 +178,11 @@ template <int G> __device__ __forceinline__ double gmin(double x) {
   if constexpr (G == 32) x = fmin(x, gxor<G, 16>(x));
   return x;
 }
+template <int G> __device__ __forceinline__ int gmin_int(int x) {
+  x = min(x, gxor<G, 1>(x)); x = min(x, gxor<G, 2>(x)); x = min(x, gxor<G, 4>(x)); x = min(x, gxor<G, 8>(x));
+  if constexpr (G == 32) x = min(x, gxor<G, 16>(x));
+  return x;
+}
 template <int G> __device__ __forceinline__ double gmax(double x) {
   x = fmax(x, gxor<G, 1>(x)); x = fmax(x, gxor<G, 2>(x)); x = fmax(x, gxor<G, 4>(x)); x = fmax(x, gxor<G, 8>(x));
   if constexpr (G == 32) x = fmax(x, gxor<G, 16>(x));
@@ -1173,43 +1178,62 @@ __device__ __forceinline__ StepOut step_body(
         }
       }
       // (slk holds the slack functions of the final qf: every pass of the loop above evaluates them before it decides to stop)
-      // most negative multiplier in A, most violated row outside A (lowest canonical index on ties)
+      // most negative multiplier in A, most violated row outside A: the VALUES first (two group minima).  Nine rounds in
+      // ten end here with neither below -eps -- certified -- and never look at a row index; only a group that has to
+      // exchange a row finds which one: the lowest canonical index among the rows attaining the minimum (numpy's argmin
+      // order), one integer group minimum each.
       double ymin = INFINITY, smin = INFINITY;
-      int yi = 0x7fffffff, si = 0x7fffffff;
+      auto s_slack = [&](int t, double fx, double fy) -> double {     // slack function of streamed row t at the stage position
+#pragma clang fp contract(off)                                        // (evaluated twice below: both must round alike)
+        double ex, ey, bb;
+        s_obs(t, ex, ey, bb);
+        return ex * fx + ey * fy - bb;
+      };
 #pragma unroll
-      for (int i = 0; i < NR; ++i) {                 // selects, no branches: (value, canonical index) lexicographic minima
-        const int ci = ci_of(i);
+      for (int i = 0; i < NR; ++i) {
         const bool ta = act[i], ti = pres[i] & !ta;
-        const double yv = ta ? y[i] : INFINITY, sv2 = ti ? slk[i] : INFINITY;
-        const bool by = (yv < ymin) | ((yv == ymin) & (ci < yi));
-        ymin = by ? yv : ymin; yi = by ? ci : yi;
-        const bool bs = (sv2 < smin) | ((sv2 == smin) & (ci < si));
-        smin = bs ? sv2 : smin; si = bs ? ci : si;
+        ymin = fmin(ymin, ta ? y[i] : INFINITY);
+        smin = fmin(smin, ti ? slk[i] : INFINITY);
       }
       if constexpr (STREAM) {
         const double fx = cx_, fy = cy_;
 #pragma unroll STREAM_UNROLL
         for (int t = 0; t < NOBS_S; ++t) {
           if ((pbits >> t) & 1u) {
-            const int ci = ci_s(t);
-            if ((abits >> t) & 1u) {
-              const double yt = lds_sz[grp][t][lane][1];
-              if (yt < ymin || (yt == ymin && ci < yi)) { ymin = yt; yi = ci; }
-            } else {
-              double ex, ey, bb;
-              s_obs(t, ex, ey, bb);
-              const double slk_t = ex * fx + ey * fy - bb;
-              if (slk_t < smin || (slk_t == smin && ci < si)) { smin = slk_t; si = ci; }
-            }
+            if ((abits >> t) & 1u) ymin = fmin(ymin, lds_sz[grp][t][lane][1]);
+            else smin = fmin(smin, s_slack(t, fx, fy));
           }
         }
       }
-      gargmin<G>(ymin, yi);
-      gargmin<G>(smin, si);
+      ymin = gmin<G>(ymin);
+      smin = gmin<G>(smin);
+      int yi = 0x7fffffff, si = 0x7fffffff;
       const double qabs = gmax<G>(fabs(qf));
-      {   // register rows: drop / add by selects (the groups of a wave take different arms)
-        const bool dropping = !fin_done & (ymin < -FIN_EPS);
-        const bool adding = !fin_done & !dropping & (smin < -FIN_EPS);
+      const bool dropping = !fin_done & (ymin < -FIN_EPS);
+      const bool adding = !fin_done & !dropping & (smin < -FIN_EPS);
+      if (__any(dropping | adding)) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          const int ci = ci_of(i);
+          const bool ta = act[i], ti = pres[i] & !ta;
+          yi = (ta & (y[i] == ymin) & (ci < yi)) ? ci : yi;
+          si = (ti & (slk[i] == smin) & (ci < si)) ? ci : si;
+        }
+        if constexpr (STREAM) {
+          const double fx = cx_, fy = cy_;
+#pragma unroll STREAM_UNROLL
+          for (int t = 0; t < NOBS_S; ++t) {
+            if ((pbits >> t) & 1u) {
+              const int ci = ci_s(t);
+              if ((abits >> t) & 1u) {
+                if (lds_sz[grp][t][lane][1] == ymin && ci < yi) yi = ci;
+              } else if (s_slack(t, fx, fy) == smin && ci < si) si = ci;
+            }
+          }
+        }
+        yi = gmin_int<G>(yi);
+        si = gmin_int<G>(si);
+        // register rows: drop / add by selects (the groups of a wave take different arms)
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
           const int ci = ci_of(i);
