@@ -50,6 +50,7 @@ constexpr int FIN_ROUNDS_LONG = 10;      // ... and for longer horizons (worse c
 constexpr double FIN_IDENT = 1e5;   // initial working set z > FIN_IDENT * s: a deliberate under-estimate (oracle docstring)
 constexpr int FIN_INNER = 6;
 constexpr double FIN_INNER_TOL = 1e-11;
+constexpr double FIN_STALL = 0.5;      // a correction that leaves more than this share of the residual has stalled
 constexpr double WARM_Z_MIN = 3.0, WARM_Z_MAX = 100.0;   // closed-loop warm start: band of the shifted previous multipliers
 constexpr int WARM_ROWS = 12;                            // register row slots a lane can hold (5 kinematic + 7 LDCBF)
 
@@ -870,17 +871,19 @@ __device__ __forceinline__ StepOut step_body(
 #pragma unroll
   for (int i = 0; i < NR; ++i) pm[i] = pres[i] ? 2.0 : 1.0;      // the Newton constant of 1/s (below)
 
+  double rp[NR];                     // primal residual s - (h - g.q) of every row, carried through the iterations
+#pragma unroll
+  for (int i = 0; i < NR; ++i) rp[i] = s[i] - slk[i];
   // Groups of a wave leave the loop independently (real divergence: a finished group's lanes are
   // simply masked off; all exchanges inside are row-local DPP / group-local LDS).
   if (lane == 0) { lds_mu[grp][0] = INFINITY; lds_mu[grp][1] = 0.0; }
   for (int it = 0; it <= P.max_iter; ++it) {
     if (__all(done)) break;
     if (!done) {
-      double rp[NR], w[NR], d[NR];
+      double w[NR], d[NR];
       double mu_l = 0.0, rpmax_l = 0.0, zmax_l = 0.0;
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
-        rp[i] = s[i] - slk[i];
         mu_l = fma(s[i], z[i], mu_l);
         rpmax_l = fmax(rpmax_l, fabs(rp[i]));
         zmax_l = fmax(zmax_l, z[i]);
@@ -1039,10 +1042,13 @@ __device__ __forceinline__ StepOut step_body(
             }
           }
           q = fma(alpha, dq, q);
-          // slack functions are affine in q: h - g.(q + a dq) = slk - a g.dq (recomputed from q in the finish)
+          // the primal residual of a row shrinks by exactly 1 - alpha along a Newton step (ds + g.dq = -rp), so it is
+          // carried by that recurrence instead of being re-formed from a slack value kept per row (one persistent double
+          // per row less; the finish recomputes the slack functions from q)
+          const double oma = 1.0 - alpha;
 #pragma unroll
           for (int i = 0; i < NR; ++i) {
-            s[i] = fma(alpha, ds[i], s[i]); z[i] = fma(alpha, dz[i], z[i]); slk[i] = fma(-alpha, dl[i], slk[i]);
+            s[i] = fma(alpha, ds[i], s[i]); z[i] = fma(alpha, dz[i], z[i]); rp[i] *= oma;
           }
         }
       }
@@ -1153,8 +1159,11 @@ __device__ __forceinline__ StepOut step_body(
         }
         const double gty = GT_rows(y, ayx, ayy);
         const double rd = var_on ? (2.0 * (qf - gc) + gty) : 0.0;
+        const double eprev = eres;
         eres = fmax(gmax<G>(fabs(rd)), gmax<G>(rmax_l));
-        const bool stop = (eres <= FIN_INNER_TOL) || (in == FIN_INNER);
+        // converged, out of corrections, or stalled on its rounding floor below what the certificate needs (an
+        // ill-conditioned working set sits at 1e-10 forever: four corrections of ~1.7 us each, per round, for nothing)
+        const bool stop = (eres <= FIN_INNER_TOL) || (in == FIN_INNER) || (eres <= FIN_EPS && eres > FIN_STALL * eprev);
         if (__all(stop || fin_done)) break;
         const double dq = solve(-rd - GT_rows(wr, awx, awy));
         double dl[NR];

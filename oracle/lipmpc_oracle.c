@@ -37,7 +37,7 @@ static const double IPM_S_FLOOR = 0.1, IPM_Z0 = 30.0, IPM_STEP_FRAC = 0.995, IPM
 static const double IPM_STALL_TOL = 1e-6;
 static const int IPM_SLOW_FROM = 8;
 static const double IPM_SLOW_RATIO = 0.9, IPM_SLOW_SIGMA = 0.5;   /* no-progress safeguard, see lipmpc_oracle.py */
-static const double FIN_RHO = 1e10, FIN_EPS = 1e-9, FIN_INNER_TOL = 1e-11, FIN_IDENT = 1e5;
+static const double FIN_RHO = 1e10, FIN_EPS = 1e-9, FIN_INNER_TOL = 1e-11, FIN_IDENT = 1e5, FIN_STALL = 0.5;
 enum { FIN_ROUNDS = 5, FIN_ROUNDS_LONG = 10, FIN_INNER = 6 };
 
 /* ---- geometry (ObstaclesUtils.py:50-109) ------------------------------------------------ */
@@ -367,6 +367,7 @@ static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, cons
       for (int i = 0; i < m; ++i) d[i] = act[i] ? FIN_RHO : 0.0;
       form_K(G, d, m, n, K);
       int fok = cholesky(K, n);
+      eres = INFINITY;
       for (int in = 0; in <= FIN_INNER; ++in) {
         mat_vec(G, qf, m, n, t);
         double rmax = 0.0;
@@ -374,8 +375,9 @@ static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, cons
         matT_vec(G, y, m, n, rd);
         double rdmax = 0.0;
         for (int i = 0; i < n; ++i) { rd[i] += 2.0 * (qf[i] - g[i]); rdmax = fmax(rdmax, fabs(rd[i])); }
+        const double eprev = eres;
         eres = fmax(rdmax, rmax);
-        if (eres <= FIN_INNER_TOL || in == FIN_INNER) break;
+        if (eres <= FIN_INNER_TOL || in == FIN_INNER || (eres <= FIN_EPS && eres > FIN_STALL * eprev)) break;
         for (int i = 0; i < m; ++i) rc[i] = FIN_RHO * w[i];
         matT_vec(G, rc, m, n, tmp);
         for (int i = 0; i < n; ++i) dq[i] = -rd[i] - tmp[i];

@@ -352,6 +352,7 @@ FIN_ROUNDS_LONG = 10   # ... and for longer horizons
 FIN_IDENT = 1e5        # initial working set: z_i > FIN_IDENT * s_i (see finish_active_set)
 FIN_INNER = 6          # max multiplier iterations per equality solve
 FIN_INNER_TOL = 1e-11
+FIN_STALL = 0.5        # a correction that leaves more than this share of the residual has stalled (stop if already <= FIN_EPS)
 WARM_Z_MIN, WARM_Z_MAX = 3.0, 100.0   # warm start of a closed loop: previous multipliers, shifted by one stage, clipped to this band
 
 
@@ -435,7 +436,7 @@ def eqp_multiplier_method(G, h, g, active, q, y_full):
     warm-started at the IPM point: K_A = 2I + rho G_A^T G_A (one Cholesky), then repeat
       rd = 2(q-g) + G_A^T y ; r = G_A q - h_A ; dq = -K_A^{-1}(rd + rho G_A^T r) ;
       q += dq ; y += rho (G_A dq + r)
-    until max(|rd|,|r|) <= 1e-11 (at most 6 times).  Dependent active rows are harmless."""
+    until max(|rd|,|r|) <= 1e-11 (at most 6 times, or until a correction stalls below 1e-9).  Dependent active rows are harmless."""
     n = G.shape[1]
     GA, hA = G[active], h[active]
     y = y_full[active].copy()
@@ -448,8 +449,10 @@ def eqp_multiplier_method(G, h, g, active, q, y_full):
     for _ in range(FIN_INNER + 1):
         rd = 2.0 * (q - g) + GA.T @ y
         r = GA @ q - hA
+        prev = res
         res = max(float(np.max(np.abs(rd))), float(np.max(np.abs(r))))
-        if res <= FIN_INNER_TOL or _ == FIN_INNER:
+        # converged, out of corrections, or stalled on its rounding floor below what the certificate needs (FIN_EPS)
+        if res <= FIN_INNER_TOL or _ == FIN_INNER or (res <= FIN_EPS and res > FIN_STALL * prev):
             break
         dq = np.linalg.solve(L.T, np.linalg.solve(L, -rd - FIN_RHO * (GA.T @ r)))
         q = q + dq

@@ -11,6 +11,11 @@ xy,nv=synth.synthetic_fields(B,n_obs,0.5,9.5,(0,0),(10,10),seed=1234)
 obs_xy=torch.as_tensor(xy,device=dev); obs_nv=torch.as_tensor(nv,device=dev)
 goal=torch.tensor([[10.,10.]],dtype=torch.float64,device=dev).repeat(B,1).contiguous()
 delta=torch.zeros((B,),dtype=torch.float64,device=dev)
+if "--bench-batch" in sys.argv:      # exactly bench.py's batch: delta = 0.3 on the second half where the start keeps that clearance
+    st0=torch.zeros((B,5),dtype=torch.float64,device=dev); ft0=torch.ones((B,),dtype=torch.int8,device=dev)
+    ce=walker.plan_step_batch(st0,goal,ft0,obs_xy,obs_nv,None,with_c_eta=True)["c_eta"]
+    clear=torch.where(obs_nv>0,torch.linalg.norm(ce[:,:,:2],dim=2),torch.full_like(ce[:,:,0],1e9)).min(dim=1).values
+    delta[B//2:]=torch.where(clear[B//2:]>0.45,0.3,0.0)
 state,foot=synth.walk_states(walker,obs_xy,obs_nv,goal,30,seed=99,delta=delta)
 def timeit(idx,label):
     idx=torch.as_tensor(idx,device=dev)
@@ -30,6 +35,8 @@ st=r['status']; it=r['iters']; rounds=r['diag'][:,0].astype(int)
 for s in np.unique(st): print('status',s,'n',(st==s).sum(),'iters mean %.1f max %d'%(it[st==s].mean(),it[st==s].max()), 'iters hist', np.bincount(it[st==s])[:40].tolist())
 print('rounds hist (status0)',np.bincount(rounds[st==0]).tolist(),'(status4)',np.bincount(rounds[st==4]).tolist())
 wave_max=it.reshape(-1,4).max(1); print('per-wave max iters: mean %.1f max %d'%(wave_max.mean(),wave_max.max()))
+W=it.reshape(-1,4); R=rounds.reshape(-1,4); tw=12+3.3*W.max(1)+5.6*R.max(1)
+for w in np.argsort(-tw)[:8]: print('  wave',w,'iters',W[w].tolist(),'rounds',R[w].tolist(),'status',st.reshape(-1,4)[w].tolist(),'model %.0f us'%tw[w])
 ok=np.where(st==0)[0]; ok=ok[:len(ok)//4*4]
 r2=timeit(ok,"status0 only")
 easy=np.where((st==0)&(rounds<=1)&(it<=14))[0]; easy=easy[:len(easy)//4*4]
