@@ -37,6 +37,8 @@ constexpr int NO_ROOT = 0x7fffffff;
 constexpr int SOLO_MIN = 48;        // a cluster of at least this many points gets the whole wave in the hull stage
 constexpr int NCC = 64;             // candidates whose bounding circle is kept for the per-pass sector test
 constexpr int VSTAGE = 64;          // hull vertices staged per cluster (v_max <= VSTAGE)
+// schedule buffer (int32): [B the order is valid for, -, order[B] (robot at launch position i), readings[B] (per robot)]
+constexpr int SCHED_VALID = 0, SCHED_ORDER = 2;
 constexpr int NRUN = RMAX / 16;      // runs of 16 consecutive readings
 constexpr int ECAP = 2 * RMAX / 4;  // edges staged per chunk of the ray phase (4 doubles each, in the hull stage's point arrays)
 static_assert(4 * VSTAGE * 2 <= 2 * RMAX, "hull staging reuses the point arrays");
@@ -85,7 +87,8 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
     int n_obs_max, int v_max, const double* __restrict__ state, const double* __restrict__ env_xy,
     const int32_t* __restrict__ env_nv, const double* __restrict__ ray_table, const double* __restrict__ noise,
     double* __restrict__ obs_xy, int32_t* __restrict__ obs_nv, double* __restrict__ c_eta, int32_t* __restrict__ n_inferred,
-    int32_t* __restrict__ overflow, double* __restrict__ hits_out, int32_t* __restrict__ labels_out, int dbg_stop) {
+    int32_t* __restrict__ overflow, double* __restrict__ hits_out, int32_t* __restrict__ labels_out,
+    int32_t* __restrict__ sched, int dbg_stop) {
   __shared__ __attribute__((aligned(16))) double pxy_[2 * RMAX];
   double* const px_ = pxy_;
   double* const py_ = pxy_ + RMAX;
@@ -103,8 +106,17 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
   __shared__ int cand_[RMAX];                    // obstacles that can be hit from here, list order
 
   const int lane = threadIdx.x;
-  const long b = blockIdx.x;
-  if (b >= B) return;
+  if ((long)blockIdx.x >= B) return;
+  // Which robot this wave scans: the block index, or -- with a schedule (include/lipmpc.h) -- the robot the order left by the
+  // previous launch puts at this position: heaviest first, by reading count.  A scan's length varies 3x with the number
+  // of readings (all-pairs clustering), 4096 robots run in two rounds on the 2048 wave slots, and a heavy robot started
+  // late sets the launch time: 241 us as the robots come, 159 us heaviest first (tools/lidar_order.py).  Any order
+  // gives the same results.
+  long b = blockIdx.x;
+  if (sched && sched[SCHED_VALID] == (int)B) {
+    const long r = sched[SCHED_ORDER + blockIdx.x];
+    if (r >= 0 && r < B) b = r;
+  }
   const double x0 = state[b * 5 + 0], y0 = state[b * 5 + 2];
   const double* exy = env_xy + b * env_stride * (long)n_env * v_env * 2;
   const int32_t* env = env_nv + b * env_stride * (long)n_env;
@@ -625,6 +637,26 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
     g += ng;
   }
   if (lane == 0) { n_inferred[b] = n_out; overflow[b] = ovf; }
+  if (sched && lane == 0) sched[SCHED_ORDER + B + b] = n_pts;      // this robot's weight for the next launch's order
+}
+
+// The order of the NEXT launch from the reading counts this launch left: robots by descending count (counting sort, one
+// workgroup; which of two equally heavy robots comes first is immaterial).
+__global__ __launch_bounds__(1024) void lidar_order_kernel(long B, int32_t* __restrict__ sched) {
+  __shared__ int cursor_[RMAX + 1];
+  const int32_t* w = sched + SCHED_ORDER + B;
+  int32_t* order = sched + SCHED_ORDER;
+  for (int k = threadIdx.x; k <= RMAX; k += blockDim.x) cursor_[k] = 0;
+  __syncthreads();
+  for (long i = threadIdx.x; i < B; i += blockDim.x) atomicAdd(&cursor_[RMAX - min(max(w[i], 0), RMAX)], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int k = 0; k <= RMAX; ++k) { const int c = cursor_[k]; cursor_[k] = run; run += c; }
+  }
+  __syncthreads();
+  for (long i = threadIdx.x; i < B; i += blockDim.x) order[atomicAdd(&cursor_[RMAX - min(max(w[i], 0), RMAX)], 1)] = (int32_t)i;
+  if (threadIdx.x == 0) sched[SCHED_VALID] = (int32_t)B;
 }
 
 }  // namespace
@@ -633,7 +665,7 @@ static int lidar_launch(int device, int64_t B, int32_t resolution, int32_t n_env
                         double lidar_range, double eps, int32_t min_samples, int32_t n_obs_max, int32_t v_max,
                         const double* state, const double* env_xy, const int32_t* env_nv, const double* ray_table,
                         const double* noise, double* obs_xy, int32_t* obs_nv, double* c_eta, int32_t* n_inferred,
-                        int32_t* overflow, double* hits, int32_t* labels, void* hip_stream) {
+                        int32_t* overflow, double* hits, int32_t* labels, int32_t* schedule, void* hip_stream) {
   if (B < 0 || resolution < 1 || resolution > RMAX || n_env < 0 || v_env < 1 || n_obs_max < 1 || v_max < 3 || v_max > VSTAGE) return LIPMPC_E_ARG;
   if (B == 0) return LIPMPC_OK;
   if (!state || !ray_table || !n_inferred || !overflow || (n_env > 0 && (!env_xy || !env_nv)) || (!obs_xy != !obs_nv) ||
@@ -649,7 +681,8 @@ static int lidar_launch(int device, int64_t B, int32_t resolution, int32_t n_env
 #endif
   hipLaunchKernelGGL(lidar_sense_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)hip_stream, (long)B, resolution, n_env,
                      v_env, (long)(env_shared ? 0 : 1), lidar_range, eps, min_samples, n_obs_max, v_max, state, env_xy, env_nv,
-                     ray_table, noise, obs_xy, obs_nv, c_eta, n_inferred, overflow, hits, labels, dbg_stop);
+                     ray_table, noise, obs_xy, obs_nv, c_eta, n_inferred, overflow, hits, labels, schedule, dbg_stop);
+  if (schedule) hipLaunchKernelGGL(lidar_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, (long)B, schedule);
   return hipGetLastError() == hipSuccess ? LIPMPC_OK : LIPMPC_E_HIP;
 }
 
@@ -661,7 +694,7 @@ extern "C" int lipmpc_lidar_sense_batch(int device, int64_t B, int32_t resolutio
                                         double* hits, int32_t* labels, void* hip_stream) {
   if (!obs_xy || !obs_nv) return LIPMPC_E_ARG;
   return lidar_launch(device, B, resolution, n_env, v_env, env_shared, lidar_range, eps, min_samples, n_obs_max, v_max, state,
-                      env_xy, env_nv, ray_table, noise, obs_xy, obs_nv, nullptr, n_inferred, overflow, hits, labels, hip_stream);
+                      env_xy, env_nv, ray_table, noise, obs_xy, obs_nv, nullptr, n_inferred, overflow, hits, labels, nullptr, hip_stream);
 }
 
 extern "C" int lipmpc_lidar_c_eta_batch(int device, int64_t B, int32_t resolution, int32_t n_env, int32_t v_env,
@@ -669,8 +702,12 @@ extern "C" int lipmpc_lidar_c_eta_batch(int device, int64_t B, int32_t resolutio
                                         int32_t n_obs_max, int32_t v_max, const double* state, const double* env_xy,
                                         const int32_t* env_nv, const double* ray_table, const double* noise,
                                         double* c_eta, int32_t* n_inferred, int32_t* overflow, double* obs_xy,
-                                        int32_t* obs_nv, double* hits, int32_t* labels, void* hip_stream) {
+                                        int32_t* obs_nv, double* hits, int32_t* labels, int32_t* schedule,
+                                        void* hip_stream) {
   if (!c_eta) return LIPMPC_E_ARG;
+  if (schedule && B > 0x3fffffff) return LIPMPC_E_UNSUPPORTED;
   return lidar_launch(device, B, resolution, n_env, v_env, env_shared, lidar_range, eps, min_samples, n_obs_max, v_max, state,
-                      env_xy, env_nv, ray_table, noise, obs_xy, obs_nv, c_eta, n_inferred, overflow, hits, labels, hip_stream);
+                      env_xy, env_nv, ray_table, noise, obs_xy, obs_nv, c_eta, n_inferred, overflow, hits, labels, schedule, hip_stream);
 }
+
+extern "C" int64_t lipmpc_lidar_schedule_words(int64_t B) { return B < 0 ? LIPMPC_E_ARG : SCHED_ORDER + 2L * B; }

@@ -60,7 +60,14 @@ class LidarSensor:
             out["labels"] = torch.empty((B, self.resolution), dtype=torch.int32, device=dev)
         return out
 
-    def sense(self, state, noise=None, with_debug=False, out=None, env_xy=None, env_nv=None, c_eta=False, rings=True):
+    def make_schedule(self, B):
+        """A zeroed schedule buffer for ``sense(..., schedule=)`` (lipmpc_lidar_c_eta_batch): hand the same buffer to every
+        scan of the same B robots and each launch starts its robots heaviest first, by the reading counts of the launch
+        before.  A scheduling hint only: results do not depend on it."""
+        return torch.zeros((int(self.lib.lipmpc_lidar_schedule_words(B)),), dtype=torch.int32, device=self.device)
+
+    def sense(self, state, noise=None, with_debug=False, out=None, env_xy=None, env_nv=None, c_eta=False, rings=True,
+              schedule=None):
         """state [B,5] device tensor; noise [B,resolution,2] or None -> dict(n_inferred, overflow[, obs_xy, obs_nv][, c_eta]
         [, hits, labels]).  ``c_eta=True``: the constraint assembly runs in the same launch (lipmpc_lidar_c_eta_batch) and
         the dict carries c_eta [B,n_obs_max,4] = (c, eta) of every inferred hull at the robot's CoM -- what
@@ -95,10 +102,13 @@ class LidarSensor:
             n_env, v_env, shared, exy, env = int(env_xy.shape[1]), int(env_xy.shape[2]), 0, env_xy, env_nv
         head = (self.device_index, B, self.resolution, n_env, v_env, shared, self.lidar_range, DBSCAN_EPS,
                 DBSCAN_MIN_SAMPLES, self.n_obs_max, self.v_max, _ptr(state), _ptr(exy), _ptr(env), _ptr(self.table), _ptr(noise))
+        if schedule is not None and (not want_ce or schedule.dtype != torch.int32 or schedule.device != dev or not schedule.is_contiguous()
+                                     or schedule.numel() != int(self.lib.lipmpc_lidar_schedule_words(B))):
+            raise ValueError("schedule: a buffer of make_schedule(B) for this B, with c_eta=True")
         if want_ce:
             rc = self.lib.lipmpc_lidar_c_eta_batch(*head, _ptr(out["c_eta"]), _ptr(out["n_inferred"]), _ptr(out["overflow"]),
                                                    _ptr(out.get("obs_xy")), _ptr(out.get("obs_nv")), _ptr(out.get("hits")),
-                                                   _ptr(out.get("labels")), C.c_void_p(stream))
+                                                   _ptr(out.get("labels")), _ptr(schedule), C.c_void_p(stream))
             _lib.check(rc, "lipmpc_lidar_c_eta_batch")
         else:
             rc = self.lib.lipmpc_lidar_sense_batch(*head, _ptr(out["obs_xy"]), _ptr(out["obs_nv"]), _ptr(out["n_inferred"]),
@@ -202,7 +212,8 @@ class UnknownEnvFleet:
         pl = dict(key=key, fl=fl, goal=torch.zeros((B, 2), **f64), delta=torch.zeros((B,), **f64) if have_delta else None,
                   sen=sn.alloc_outputs(B, rings=False, c_eta=True),      # hulls stay in the scan kernel: only (c, eta) rows reach HBM
                   out=sv.alloc_outputs(B), nbuf=None if noise_mode == "none" else torch.zeros((B, sn.resolution, 2), **f64),
-                  gen=torch.Generator(device=dev) if noise_mode == "seeded" else None, graph=None)
+                  gen=torch.Generator(device=dev) if noise_mode == "seeded" else None, graph=None,
+                  sched=sn.make_schedule(B))                 # heaviest-first start order, from one sample to the next
         self._plan = pl
         return pl
 
@@ -238,7 +249,7 @@ class UnknownEnvFleet:
             # and the trajectory row: one bookkeeping launch (lipmpc_fleet_update_batch)
             if gen is not None:
                 nbuf.normal_(0.0, NOISE_STD, generator=gen)
-            sn.sense(fl["state"], nbuf, out=sen)
+            sn.sense(fl["state"], nbuf, out=sen, schedule=pl["sched"])
             sv.plan_step_batch_c_eta(fl["state"], pl["goal"], fl["first_foot"], sen["c_eta"], pl["delta"], out=out)
             sv.fleet_update(fl, out, overflow=sen["overflow"], stop_obj=stop_obj)
 

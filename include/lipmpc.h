@@ -215,13 +215,21 @@ int lipmpc_lidar_sense_batch(int device, int64_t B, int32_t resolution, int32_t 
  *  c_eta [B,n_obs_max,4] (c_x, c_y, eta_x, eta_y) per inferred obstacle, cluster order; empty slots all zero;
  *        eta = NaN where the geometry is degenerate (CoM on the hull boundary, zero-length hull edge)
  *  n_inferred [B], overflow [B] as lipmpc_lidar_sense_batch
- *  obs_xy / obs_nv: the rings as well, or both NULL;  hits, labels: or NULL */
+ *  obs_xy / obs_nv: the rings as well, or both NULL;  hits, labels: or NULL
+ *  schedule: NULL, or a device buffer of lipmpc_lidar_schedule_words(B) int32, ZEROED once by the caller and then handed to
+ *        every launch of the same robots (a closed loop's samples).  A scan's length grows with its reading count (all-pairs
+ *        clustering) and 4096 robots run in two rounds of waves, so a heavy robot started late sets the launch time; each
+ *        launch leaves there its robots' reading counts and (one small extra kernel) the order -- heaviest first -- in
+ *        which the next launch starts them: 0.16 instead of 0.24 ms per 4096 robots when the robots keep their weights.
+ *        A pure scheduling hint: a buffer that holds no order for this B (first launch, another B) means index order, and
+ *        every order gives the same results.  Launches sharing a schedule must be stream-ordered; it replays in a graph. */
 int lipmpc_lidar_c_eta_batch(int device, int64_t B, int32_t resolution, int32_t n_env, int32_t v_env,
                              int32_t env_shared, double lidar_range, double eps, int32_t min_samples,
                              int32_t n_obs_max, int32_t v_max, const double* state, const double* env_xy,
                              const int32_t* env_nv, const double* ray_table, const double* noise,
                              double* c_eta, int32_t* n_inferred, int32_t* overflow, double* obs_xy,
-                             int32_t* obs_nv, double* hits, int32_t* labels, void* hip_stream);
+                             int32_t* obs_nv, double* hits, int32_t* labels, int32_t* schedule, void* hip_stream);
+int64_t lipmpc_lidar_schedule_words(int64_t B);
 
 const char* lipmpc_strerror(int code);
 int lipmpc_version(void);

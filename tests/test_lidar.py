@@ -374,6 +374,19 @@ def test_gpu_constraint_assembly_fused_into_the_scan(golden_dir):
     for k in ("U", "X", "obj"):
         assert torch.equal(ref[k][ok], got[k][ok]), k
     assert int(ok.sum()) > 0.6 * B
+    # the heaviest-first schedule is a pure scheduling hint: first launch (empty schedule = index order), second launch
+    # (ordered by the first one's reading counts), a launch with another batch size in between -- same answers
+    sched = sensor.make_schedule(B)
+    for rep in range(3):
+        got_s = sensor.sense(d_st, noise, c_eta=True, rings=False, schedule=sched)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.nan_to_num(got_s["c_eta"], nan=7.0), torch.nan_to_num(lean["c_eta"], nan=7.0)), rep
+        assert torch.equal(got_s["n_inferred"], lean["n_inferred"]) and torch.equal(got_s["overflow"], lean["overflow"])
+        sc = sched.cpu().numpy()
+        assert sc[0] == B and np.array_equal(np.sort(sc[2:2 + B]), np.arange(B))               # a complete order of the B robots ...
+        assert np.all(np.diff(sc[2 + B:][sc[2:2 + B]]) <= 0)                                   # ... by descending reading count
+    with pytest.raises(ValueError):
+        sensor.sense(d_st[:100].contiguous(), noise[:100].contiguous(), c_eta=True, schedule=sched)
     # a NaN normal in the rows (degenerate geometry met by the producer) is reported as DEGENERATE, like the ring front end
     ce = lean["c_eta"][:4].clone(); ce[1, 0, 2] = float("nan")
     r = sv.plan_step_batch_c_eta(d_st[:4].contiguous(), goal[:4].contiguous(), foot[:4].contiguous(), ce.contiguous())
