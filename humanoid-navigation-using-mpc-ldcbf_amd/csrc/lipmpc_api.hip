@@ -77,6 +77,7 @@ struct lipmpc_handle {
   int device;
   int G;
   int nobs_l;
+  int nvar;     // variable slots of the factorisation: G, or 8 (horizons up to 4, register-row instantiations)
 };
 
 extern "C" {
@@ -110,6 +111,7 @@ int lipmpc_create(const lipmpc_params* p, int device, lipmpc_handle** out) {
   h->G = (p->N <= 8) ? 16 : 32;
   const int need = (p->n_obs_max + 1) / 2;
   h->nobs_l = need == 0 ? 0 : need <= 2 ? 2 : need <= 5 ? 5 : need <= 7 ? 7 : need <= 13 ? 13 : 25;
+  h->nvar = (h->G == 16 && p->N <= 4 && h->nobs_l <= 7) ? 8 : h->G;
   KArgs& k = h->k;
   k.N = p->N; k.n_obs = p->n_obs_max; k.nvert_max = p->v_max; k.max_iter = p->max_iter; k.flags = p->flags;
   k.fin_rounds = p->finish_rounds > 0 ? p->finish_rounds : (p->N <= 8 ? FIN_ROUNDS : FIN_ROUNDS_LONG);
@@ -126,9 +128,9 @@ int lipmpc_create(const lipmpc_params* p, int device, lipmpc_handle** out) {
 
 void lipmpc_destroy(lipmpc_handle* h) { free(h); }
 
-#define LAUNCH(GG, NL)                                                                                         \
-  launch_plan_step<GG, NL>(h->k, (long)B, state, goal, first_foot, delta, obs_xy, obs_nv, U, X, theta, omega, obj, \
-                           status, iters, (unsigned long long*)active, c_eta, diag, bounds, c_eta_in, stream)
+#define LAUNCH(GG, NL, NV)                                                                                     \
+  launch_plan_step<GG, NL, NV>(h->k, (long)B, state, goal, first_foot, delta, obs_xy, obs_nv, U, X, theta, omega, obj, \
+                               status, iters, (unsigned long long*)active, c_eta, diag, bounds, c_eta_in, stream)
 
 static int plan_step_impl(lipmpc_handle* h, int64_t B, const double* state, const double* goal,
                           const int8_t* first_foot, const double* delta, const double* obs_xy,
@@ -142,23 +144,30 @@ static int plan_step_impl(lipmpc_handle* h, int64_t B, const double* state, cons
   if (h->p.n_obs_max > 0 && !c_eta_in && (!obs_xy || !obs_nv)) return LIPMPC_E_ARG;
   if (hipSetDevice(h->device) != hipSuccess) return LIPMPC_E_HIP;
   hipStream_t stream = (hipStream_t)hip_stream;
-  if (h->G == 16) {
+  if (h->G == 16 && h->nvar == 8) {
     switch (h->nobs_l) {
-      case 0: LAUNCH(16, 0); break;
-      case 2: LAUNCH(16, 2); break;
-      case 5: LAUNCH(16, 5); break;
-      case 7: LAUNCH(16, 7); break;
-      case 13: LAUNCH(16, 13); break;
-      default: LAUNCH(16, 25); break;
+      case 0: LAUNCH(16, 0, 8); break;
+      case 2: LAUNCH(16, 2, 8); break;
+      case 5: LAUNCH(16, 5, 8); break;
+      default: LAUNCH(16, 7, 8); break;
+    }
+  } else if (h->G == 16) {
+    switch (h->nobs_l) {
+      case 0: LAUNCH(16, 0, 16); break;
+      case 2: LAUNCH(16, 2, 16); break;
+      case 5: LAUNCH(16, 5, 16); break;
+      case 7: LAUNCH(16, 7, 16); break;
+      case 13: LAUNCH(16, 13, 16); break;
+      default: LAUNCH(16, 25, 16); break;
     }
   } else {
     switch (h->nobs_l) {
-      case 0: LAUNCH(32, 0); break;
-      case 2: LAUNCH(32, 2); break;
-      case 5: LAUNCH(32, 5); break;
-      case 7: LAUNCH(32, 7); break;
-      case 13: LAUNCH(32, 13); break;
-      default: LAUNCH(32, 25); break;
+      case 0: LAUNCH(32, 0, 32); break;
+      case 2: LAUNCH(32, 2, 32); break;
+      case 5: LAUNCH(32, 5, 32); break;
+      case 7: LAUNCH(32, 7, 32); break;
+      case 13: LAUNCH(32, 13, 32); break;
+      default: LAUNCH(32, 25, 32); break;
     }
   }
   return hipGetLastError() == hipSuccess ? LIPMPC_OK : LIPMPC_E_HIP;
@@ -182,9 +191,9 @@ int lipmpc_plan_step_batch_c_eta(lipmpc_handle* h, int64_t B, const double* stat
                         iters, active, nullptr, diag, bounds, hip_stream);
 }
 
-#define LAUNCH_RO(GG, NL)                                                                                        \
-  launch_rollout<GG, NL>(h->k, (long)B, k_max, mpc_step, stop_obj, state0, goal, first_foot, delta, obs_xy, obs_nv, \
-                         X_pred, U_pred, n_steps, last_status, total_iters, bounds, stream)
+#define LAUNCH_RO(GG, NL, NV)                                                                                    \
+  launch_rollout<GG, NL, NV>(h->k, (long)B, k_max, mpc_step, stop_obj, state0, goal, first_foot, delta, obs_xy, obs_nv, \
+                             X_pred, U_pred, n_steps, last_status, total_iters, bounds, stream)
 
 int lipmpc_rollout_batch(lipmpc_handle* h, int64_t B, int32_t k_max, int32_t mpc_step, double stop_obj,
                          const double* state0, const double* goal, const int8_t* first_foot, const double* delta,
@@ -197,23 +206,30 @@ int lipmpc_rollout_batch(lipmpc_handle* h, int64_t B, int32_t k_max, int32_t mpc
   if (h->p.n_obs_max > 0 && (!obs_xy || !obs_nv)) return LIPMPC_E_ARG;
   if (hipSetDevice(h->device) != hipSuccess) return LIPMPC_E_HIP;
   hipStream_t stream = (hipStream_t)hip_stream;
-  if (h->G == 16) {
+  if (h->G == 16 && h->nvar == 8) {
     switch (h->nobs_l) {
-      case 0: LAUNCH_RO(16, 0); break;
-      case 2: LAUNCH_RO(16, 2); break;
-      case 5: LAUNCH_RO(16, 5); break;
-      case 7: LAUNCH_RO(16, 7); break;
-      case 13: LAUNCH_RO(16, 13); break;
-      default: LAUNCH_RO(16, 25); break;
+      case 0: LAUNCH_RO(16, 0, 8); break;
+      case 2: LAUNCH_RO(16, 2, 8); break;
+      case 5: LAUNCH_RO(16, 5, 8); break;
+      default: LAUNCH_RO(16, 7, 8); break;
+    }
+  } else if (h->G == 16) {
+    switch (h->nobs_l) {
+      case 0: LAUNCH_RO(16, 0, 16); break;
+      case 2: LAUNCH_RO(16, 2, 16); break;
+      case 5: LAUNCH_RO(16, 5, 16); break;
+      case 7: LAUNCH_RO(16, 7, 16); break;
+      case 13: LAUNCH_RO(16, 13, 16); break;
+      default: LAUNCH_RO(16, 25, 16); break;
     }
   } else {
     switch (h->nobs_l) {
-      case 0: LAUNCH_RO(32, 0); break;
-      case 2: LAUNCH_RO(32, 2); break;
-      case 5: LAUNCH_RO(32, 5); break;
-      case 7: LAUNCH_RO(32, 7); break;
-      case 13: LAUNCH_RO(32, 13); break;
-      default: LAUNCH_RO(32, 25); break;
+      case 0: LAUNCH_RO(32, 0, 32); break;
+      case 2: LAUNCH_RO(32, 2, 32); break;
+      case 5: LAUNCH_RO(32, 5, 32); break;
+      case 7: LAUNCH_RO(32, 7, 32); break;
+      case 13: LAUNCH_RO(32, 13, 32); break;
+      default: LAUNCH_RO(32, 25, 32); break;
     }
   }
   return hipGetLastError() == hipSuccess ? LIPMPC_OK : LIPMPC_E_HIP;

@@ -1,10 +1,10 @@
 // lipmpc_inst.hip — one explicit instantiation of the step kernel per object file:
-// compiled with -DINST_G=<16|32> -DINST_NL=<0|2|5|7|13|25> (see Makefile).
+// compiled with -DINST_G=<16|32> -DINST_NL=<0|2|5|7|13|25> -DINST_NV=<variable slots: INST_G, or 8 for horizons up to 4> (see Makefile).
 #include "lipmpc_kernel.hpp"
 
 namespace lipmpc_dev {
 
-template <int G, int NOBS_L>
+template <int G, int NOBS_L, int NVAR>
 void launch_plan_step(const KArgs& k, long B, const double* state, const double* goal, const int8_t* first_foot,
                       const double* delta, const double* obs_xy, const int32_t* obs_nv, double* U, double* X,
                       double* theta, double* omega, double* obj, int32_t* status, int32_t* iters,
@@ -12,27 +12,27 @@ void launch_plan_step(const KArgs& k, long B, const double* state, const double*
                       const double* c_eta_in, hipStream_t stream) {
   constexpr int GPW = WAVE / G;
   const unsigned blocks = (unsigned)((B + GPW - 1) / GPW);
-  hipLaunchKernelGGL((plan_step_kernel<G, NOBS_L>), dim3(blocks), dim3(WAVE), 0, stream, k, B, state, goal, first_foot,
+  hipLaunchKernelGGL((plan_step_kernel<G, NOBS_L, NVAR>), dim3(blocks), dim3(WAVE), 0, stream, k, B, state, goal, first_foot,
                      delta, obs_xy, obs_nv, U, X, theta, omega, obj, status, iters, active, c_eta, diag, bounds, c_eta_in);
 }
 
-template void launch_plan_step<INST_G, INST_NL>(const KArgs&, long, const double*, const double*, const int8_t*,
+template void launch_plan_step<INST_G, INST_NL, INST_NV>(const KArgs&, long, const double*, const double*, const int8_t*,
                                                 const double*, const double*, const int32_t*, double*, double*,
                                                 double*, double*, double*, int32_t*, int32_t*, unsigned long long*,
                                                 double*, double*, const double*, const double*, hipStream_t);
 
-template <int G, int NOBS_L>
+template <int G, int NOBS_L, int NVAR>
 void launch_rollout(const KArgs& k, long B, int k_max, int mpc_step, double stop_obj, const double* state0,
                     const double* goal, const int8_t* first_foot, const double* delta, const double* obs_xy,
                     const int32_t* obs_nv, double* X_pred, double* U_pred, int32_t* n_steps, int32_t* last_status,
                     int32_t* total_iters, const double* bounds, hipStream_t stream) {
   constexpr int GPW = WAVE / G;
   const unsigned blocks = (unsigned)((B + GPW - 1) / GPW);
-  hipLaunchKernelGGL((rollout_kernel<G, NOBS_L>), dim3(blocks), dim3(WAVE), 0, stream, k, B, k_max, mpc_step, stop_obj,
+  hipLaunchKernelGGL((rollout_kernel<G, NOBS_L, NVAR>), dim3(blocks), dim3(WAVE), 0, stream, k, B, k_max, mpc_step, stop_obj,
                      state0, goal, first_foot, delta, obs_xy, obs_nv, X_pred, U_pred, n_steps, last_status, total_iters, bounds);
 }
 
-template void launch_rollout<INST_G, INST_NL>(const KArgs&, long, int, int, double, const double*, const double*,
+template void launch_rollout<INST_G, INST_NL, INST_NV>(const KArgs&, long, int, int, double, const double*, const double*,
                                               const int8_t*, const double*, const double*, const int32_t*, double*,
                                               double*, int32_t*, int32_t*, int32_t*, const double*, hipStream_t);
 

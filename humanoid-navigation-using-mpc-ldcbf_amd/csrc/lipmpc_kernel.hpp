@@ -372,15 +372,20 @@ __device__ __forceinline__ void load_bounds(const KArgs& P, const double* __rest
 }
 
 // The whole MPC step of one problem on one group of G lanes.  Output pointers may be null.
-template <int G, int NOBS_L>
+template <int G, int NOBS_L, int NVAR = G>
 __device__ __forceinline__ StepOut step_body(
     const KArgs& P, const StepIn& in, const double* __restrict__ obs_xy, const int32_t* __restrict__ obs_nv,
     double* __restrict__ U, double* __restrict__ X, double* __restrict__ theta_out,
     double* __restrict__ omega_out, double* __restrict__ obj_out, int32_t* __restrict__ status_out,
     int32_t* __restrict__ iters_out, unsigned long long* __restrict__ active_out, double* __restrict__ c_eta,
     double* __restrict__ diag, const double* __restrict__ c_eta_in = nullptr, WarmIO* __restrict__ warm = nullptr) {
-  constexpr int NMAX = G / 2;          // stages a group can hold
-  constexpr int NV = G;                // variable slots (lanes)
+  // NVAR = variable slots of the factorisation: G (every lane holds a variable: horizons up to G / 2), or 8 on a 16-lane
+  // group for horizons up to 4 -- the reference's default N_horizon = 3, BASELINE config 5 -- where lanes 8..15 hold no
+  // variable, their rows of K are 2I and decouple, and the factorisation / substitutions run on the leading 8 x 8 block
+  static_assert(NVAR == G || (G == 16 && NVAR == 8), "variable slots: all lanes, or the first 8 of a 16-lane group");
+  constexpr int NMAX = NVAR / 2;       // stages the factorisation holds (N <= NMAX, checked by the host)
+  constexpr int LMAX = G / 2;          // stages by lane position (a = lane >> 1 runs up to here)
+  constexpr int NV = NVAR;             // variable slots
   constexpr int GPW = 64 / G;          // groups per wavefront
   // LDCBF rows of a lane live in registers for small obstacle sets (NOBS_R of them) and are STREAMED for
   // large ones: only (s, z) per row is kept, in LDS, and every pass over the rows recomputes the rest from
@@ -403,7 +408,7 @@ __device__ __forceinline__ StepOut step_body(
   constexpr int RING_CAP = (G == 16) ? 64 : 256;
   __shared__ double lds_ring[GPW][MAXOBS > 0 ? RING_CAP : 1][2];
   __shared__ double lds_obs[GPW][MAXOBS > 0 ? MAXOBS : 1][4];   // eta_x, eta_y, b = eta.c + delta, h0
-  __shared__ double lds_P[GPW][NMAX][2][2];                     // P_b blocks of the velocity part of K
+  __shared__ double lds_P[GPW][LMAX][2][2];                     // P_b blocks of the velocity part of K
   __shared__ unsigned long long lds_act[GPW][MAXWORDS];
   __shared__ int lds_flag[GPW];
   __shared__ double lds_mu[GPW][2];      // no-progress safeguard: mu of the previous iteration, sigma floor of this one
@@ -662,7 +667,7 @@ __device__ __forceinline__ StepOut step_body(
         const double nf = zero_unless(ln > j, Krow[j] * -ip);
         ipiv = (ln == j) ? ip : ipiv;
         Xl[j] = nf;
-        if constexpr (NV == 16) FactorStep<j>::run(Krow, nf);
+        FactorStep<NV, j>::run(Krow, nf);
       } else if constexpr (G == 16) {
         const double pj = gbcast<G, j>(Krow[j]);
         ok = ok && (pj > 0.0);
@@ -708,10 +713,8 @@ __device__ __forceinline__ StepOut step_body(
       // forward: b_l += Xl_l[j] b_j (lanes l > j); lane j's b is final after step j-1.  backward on x = w - ipiv acc:
       // x_l += Yu_l[j] x_j (lanes l < j), lane j final once the columns above it are done.  One instruction per step.
       dpp_fence();
-      if constexpr (NV == 16) {
-        b = solve_forward_chain(b, Xl);
-        return solve_backward_chain(b * ipiv, Yu);
-      } else return b;
+      b = solve_forward_chain(b, Xl);
+      return solve_backward_chain(b * ipiv, Yu);
     } else if constexpr (G == 16) {
       // forward Lt w = b: w_j = b_j / p_j, b_l -= Lt[l][j] w_j (l > j); lane j's b is final after step j
       static_for<0, NV>([&](auto jc) {
@@ -1342,7 +1345,7 @@ __device__ __forceinline__ StepOut step_body(
 // ------------------------------------------------------------------------------------------
 // kernel 1: one MPC step for B problems (lipmpc_plan_step_batch)
 // ------------------------------------------------------------------------------------------
-template <int G, int NOBS_L>
+template <int G, int NOBS_L, int NVAR>
 __global__ __launch_bounds__(WAVE) void plan_step_kernel(
     KArgs P, long B, const double* __restrict__ state, const double* __restrict__ goal,
     const int8_t* __restrict__ first_foot, const double* __restrict__ delta_in,
@@ -1366,7 +1369,7 @@ __global__ __launch_bounds__(WAVE) void plan_step_kernel(
   in.gx = goal[pb * 2 + 0]; in.gy = goal[pb * 2 + 1];
   in.foot0 = (double)first_foot[pb];
   in.delta = delta_in ? delta_in[pb] : 0.0;
-  step_body<G, NOBS_L>(P, in, obs_xy, obs_nv, U, X, theta_out, omega_out, obj_out, status_out, iters_out, active_out,
+  step_body<G, NOBS_L, NVAR>(P, in, obs_xy, obs_nv, U, X, theta_out, omega_out, obj_out, status_out, iters_out, active_out,
                        c_eta, diag, c_eta_in);
 }
 
@@ -1378,7 +1381,7 @@ __global__ __launch_bounds__(WAVE) void plan_step_kernel(
 // number floor(k / mpc_step) alternates (:104-108, 401-403).  A failed solve ends the robot's run (:419-429).
 // Each group owns one robot for the whole run: no host round trip, no batch-wide barrier per step.
 // ------------------------------------------------------------------------------------------
-template <int G, int NOBS_L>
+template <int G, int NOBS_L, int NVAR>
 __global__ __launch_bounds__(WAVE) void rollout_kernel(
     KArgs P, long B, int k_max, int mpc_step, double stop_obj, const double* __restrict__ state0,
     const double* __restrict__ goal, const int8_t* __restrict__ first_foot, const double* __restrict__ delta_in,
@@ -1419,7 +1422,7 @@ __global__ __launch_bounds__(WAVE) void rollout_kernel(
       const bool is_mpc = (k % mpc_step) == 0;
       double theta1, omega0;
       if (is_mpc) {     // group-uniform (k and mpc_step are wave-uniform)
-        const StepOut r = step_body<G, NOBS_L>(P, in, obs_xy, obs_nv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+        const StepOut r = step_body<G, NOBS_L, NVAR>(P, in, obs_xy, obs_nv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                                                nullptr, nullptr, nullptr, nullptr, nullptr, &ws);
         if (use_warm) ws.have = true;             // (a failed solve ends the run anyway)
         st_last = r.status;
@@ -1455,13 +1458,13 @@ __global__ __launch_bounds__(WAVE) void rollout_kernel(
 }
 
 // host-side launcher of one instantiation (defined in lipmpc_inst.hip, one object per (G, NOBS_L))
-template <int G, int NOBS_L>
+template <int G, int NOBS_L, int NVAR>
 void launch_plan_step(const KArgs& k, long B, const double* state, const double* goal, const int8_t* first_foot,
                       const double* delta, const double* obs_xy, const int32_t* obs_nv, double* U, double* X,
                       double* theta, double* omega, double* obj, int32_t* status, int32_t* iters,
                       unsigned long long* active, double* c_eta, double* diag, const double* bounds,
                       const double* c_eta_in, hipStream_t stream);
-template <int G, int NOBS_L>
+template <int G, int NOBS_L, int NVAR>
 void launch_rollout(const KArgs& k, long B, int k_max, int mpc_step, double stop_obj, const double* state0,
                     const double* goal, const int8_t* first_foot, const double* delta, const double* obs_xy,
                     const int32_t* obs_nv, double* X_pred, double* U_pred, int32_t* n_steps, int32_t* last_status,

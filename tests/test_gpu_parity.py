@@ -349,11 +349,11 @@ def test_limit_cycle_case_on_gpu(golden_dir):
     assert np.max(np.abs(res["U"][0] - r["U"])) < 1e-8
 
 
-@pytest.mark.parametrize("N", [6, 12])
-@pytest.mark.parametrize("n_obs", [0, 3, 9, 14, 22, 40])
+@pytest.mark.parametrize("N,n_obs", [(N, n) for N in (6, 12) for n in (0, 3, 9, 14, 22, 40)] + [(3, n) for n in (0, 3, 9, 14)])
 def test_every_instantiation_against_c_oracle(N, n_obs):
-    """One small batch through each of the twelve kernel instantiations (16 / 32 lanes per problem x 0, 2, 5, 7
-    register row slots and 13, 25 streamed ones), step kernel and rollout kernel: statuses as the C oracle's,
+    """One small batch through each of the sixteen kernel instantiations (16 / 32 lanes per problem x 0, 2, 5, 7
+    register row slots and 13, 25 streamed ones, + the four half-size factorisations horizons up to 4 run on), step kernel
+    and rollout kernel: statuses as the C oracle's,
     footsteps within 1e-5; the rollout's first sample equals the step kernel's answer.  (The compiler has
     miscompiled single instantiations after unrelated source changes — every one of them is pinned here.)"""
     import c_oracle
