@@ -235,6 +235,24 @@ int lipmpc_rollout_batch(lipmpc_handle* h, int64_t B, int32_t k_max, int32_t mpc
   return hipGetLastError() == hipSuccess ? LIPMPC_OK : LIPMPC_E_HIP;
 }
 
+int lipmpc_sense_plan_step_batch(lipmpc_handle* h, int64_t B, int32_t resolution, int32_t n_env, int32_t v_env,
+                                 int32_t env_shared, double lidar_range, double eps, int32_t min_samples,
+                                 const double* state, const double* goal, const int8_t* first_foot, const double* delta,
+                                 const double* env_xy, const int32_t* env_nv, const double* ray_table, const double* noise,
+                                 double* c_eta, int32_t* n_inferred, int32_t* overflow, int32_t* schedule,
+                                 double* U, double* X, double* theta, double* omega, double* obj, int32_t* status,
+                                 int32_t* iters, uint64_t* active, double* diag, const double* bounds, void* hip_stream) {
+  if (!h || B < 0) return LIPMPC_E_ARG;
+  if (h->p.n_obs_max < 1) return LIPMPC_E_UNSUPPORTED;        // a handle without obstacle slots has nothing to sense into
+  if (!c_eta || !goal || !first_foot || !U || !X || !theta || !omega || !obj || !status || !iters || !active) return LIPMPC_E_ARG;
+  const int rc = lipmpc_lidar_c_eta_batch(h->device, B, resolution, n_env, v_env, env_shared, lidar_range, eps, min_samples,
+                                          h->p.n_obs_max, h->p.v_max, state, env_xy, env_nv, ray_table, noise, c_eta, n_inferred,
+                                          overflow, nullptr, nullptr, nullptr, nullptr, schedule, hip_stream);
+  if (rc != LIPMPC_OK) return rc;
+  return lipmpc_plan_step_batch_c_eta(h, B, state, goal, first_foot, delta, c_eta, U, X, theta, omega, obj, status, iters, active,
+                                      diag, bounds, hip_stream);
+}
+
 int lipmpc_advance_batch(lipmpc_handle* h, int64_t B, double* state, int8_t* first_foot, const double* U,
                          const double* theta, const int32_t* status, void* hip_stream) {
   if (!h || B < 0) return LIPMPC_E_ARG;

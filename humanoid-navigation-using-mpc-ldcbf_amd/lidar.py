@@ -118,6 +118,44 @@ class LidarSensor:
         return out
 
 
+    def sense_plan_step(self, solver, state, goal, first_foot, noise=None, delta=None, sen=None, out=None, schedule=None,
+                        bounds=None):
+        """One MPC step of the unknown-environment variant in one C call (lipmpc_sense_plan_step_batch): scan + constraint
+        assembly, then ``solver``'s step against the assembled half-spaces.  ``solver``: a BatchedLipMpc whose
+        n_obs_max / v_max are this sensor's.  Returns (sen, out) as ``sense(..., c_eta=True, rings=False)`` and
+        ``plan_step_batch_c_eta`` would."""
+        P = solver.params
+        if P.n_obs_max != self.n_obs_max or P.v_max != self.v_max or solver.device != self.device:
+            raise ValueError("solver and sensor must share n_obs_max, v_max and the device")
+        B = solver._check_inputs(state, goal, first_foot, None, None, delta, need_obstacles=False)
+        solver._check_optional(bounds, (B, 4), torch.float64, "bounds")
+        if sen is None:
+            sen = self.alloc_outputs(B, rings=False, c_eta=True)
+        if out is None:
+            out = solver.alloc_outputs(B)
+        else:
+            solver._check_outputs(out, B)
+        for name, shape, dt in (("c_eta", (B, self.n_obs_max, 4), torch.float64), ("n_inferred", (B,), torch.int32), ("overflow", (B,), torch.int32)):
+            t = sen.get(name)
+            if t is None or tuple(t.shape) != shape or t.dtype != dt or t.device != self.device or not t.is_contiguous():
+                raise ValueError(f"sen['{name}']: expected contiguous {dt} {shape} on {self.device}")
+        if noise is not None and (tuple(noise.shape) != (B, self.resolution, 2) or noise.dtype != torch.float64
+                                  or noise.device != self.device or not noise.is_contiguous()):
+            raise ValueError(f"noise: expected contiguous float64 {(B, self.resolution, 2)} on {self.device}")
+        if schedule is not None and (schedule.dtype != torch.int32 or schedule.device != self.device or not schedule.is_contiguous()
+                                     or schedule.numel() != int(self.lib.lipmpc_lidar_schedule_words(B))):
+            raise ValueError("schedule: a buffer of make_schedule(B) for this B")
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.lib.lipmpc_sense_plan_step_batch(
+            solver._h, B, self.resolution, self.n_env, self.v_env, 1, self.lidar_range, DBSCAN_EPS, DBSCAN_MIN_SAMPLES,
+            _ptr(state), _ptr(goal), _ptr(first_foot), _ptr(delta), _ptr(self.env_xy), _ptr(self.env_nv), _ptr(self.table),
+            _ptr(noise), _ptr(sen["c_eta"]), _ptr(sen["n_inferred"]), _ptr(sen["overflow"]), _ptr(schedule),
+            _ptr(out["U"]), _ptr(out["X"]), _ptr(out["theta"]), _ptr(out["omega"]), _ptr(out["obj"]), _ptr(out["status"]),
+            _ptr(out["iters"]), _ptr(out["active"]), _ptr(out.get("diag")), _ptr(bounds), C.c_void_p(stream))
+        _lib.check(rc, "lipmpc_sense_plan_step_batch")
+        return sen, out
+
+
 class HumanoidMPCUnknownEnvironment(HumanoidMPC):
     """The robot only perceives obstacles through its LiDAR (HumanoidMPCUnknownEnvironment.py:13-28): every sample the
     obstacle set is re-inferred on the GPU and handed to the step solver.  ``noise_seed`` seeds the readings' noise
@@ -249,8 +287,7 @@ class UnknownEnvFleet:
             # and the trajectory row: one bookkeeping launch (lipmpc_fleet_update_batch)
             if gen is not None:
                 nbuf.normal_(0.0, NOISE_STD, generator=gen)
-            sn.sense(fl["state"], nbuf, out=sen, schedule=pl["sched"])
-            sv.plan_step_batch_c_eta(fl["state"], pl["goal"], fl["first_foot"], sen["c_eta"], pl["delta"], out=out)
+            sn.sense_plan_step(sv, fl["state"], pl["goal"], fl["first_foot"], nbuf, pl["delta"], sen=sen, out=out, schedule=pl["sched"])
             sv.fleet_update(fl, out, overflow=sen["overflow"], stop_obj=stop_obj)
 
         if use_graph and pl["graph"] is None:

@@ -231,6 +231,19 @@ int lipmpc_lidar_c_eta_batch(int device, int64_t B, int32_t resolution, int32_t 
                              int32_t* obs_nv, double* hits, int32_t* labels, int32_t* schedule, void* hip_stream);
 int64_t lipmpc_lidar_schedule_words(int64_t B);
 
+/* One MPC step of the unknown-environment variant in ONE call (what HumanoidMPCUnknownEnvironment does per step,
+ * HumanoidMPCUnknownEnvironment.py:30-68 + HumanoidMpc.py:387-418): lipmpc_lidar_c_eta_batch (scan, clusters, hulls,
+ * closest point / normal: one launch, n_obs_max / v_max from the handle) followed on the same stream by
+ * lipmpc_plan_step_batch_c_eta against those half-spaces.  c_eta [B,n_obs_max,4] is the hand-over buffer (and an output);
+ * schedule as in lipmpc_lidar_c_eta_batch or NULL; every other argument as in the two functions. */
+int lipmpc_sense_plan_step_batch(lipmpc_handle* h, int64_t B, int32_t resolution, int32_t n_env, int32_t v_env,
+                                 int32_t env_shared, double lidar_range, double eps, int32_t min_samples,
+                                 const double* state, const double* goal, const int8_t* first_foot, const double* delta,
+                                 const double* env_xy, const int32_t* env_nv, const double* ray_table, const double* noise,
+                                 double* c_eta, int32_t* n_inferred, int32_t* overflow, int32_t* schedule,
+                                 double* U, double* X, double* theta, double* omega, double* obj, int32_t* status,
+                                 int32_t* iters, uint64_t* active, double* diag, const double* bounds, void* hip_stream);
+
 const char* lipmpc_strerror(int code);
 int lipmpc_version(void);
 

@@ -387,6 +387,13 @@ def test_gpu_constraint_assembly_fused_into_the_scan(golden_dir):
         assert np.all(np.diff(sc[2 + B:][sc[2:2 + B]]) <= 0)                                   # ... by descending reading count
     with pytest.raises(ValueError):
         sensor.sense(d_st[:100].contiguous(), noise[:100].contiguous(), c_eta=True, schedule=sched)
+    # the whole step of the unknown-environment variant in one C call
+    sen1, out1 = sensor.sense_plan_step(sv, d_st, goal, foot, noise, delta, schedule=sched)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(sen1["c_eta"], nan=7.0), torch.nan_to_num(lean["c_eta"], nan=7.0))
+    for k in ("status", "iters", "active"):
+        assert torch.equal(out1[k], got[k]), k
+    assert torch.equal(out1["U"][ok], got["U"][ok])
     # a NaN normal in the rows (degenerate geometry met by the producer) is reported as DEGENERATE, like the ring front end
     ce = lean["c_eta"][:4].clone(); ce[1, 0, 2] = float("nan")
     r = sv.plan_step_batch_c_eta(d_st[:4].contiguous(), goal[:4].contiguous(), foot[:4].contiguous(), ce.contiguous())
