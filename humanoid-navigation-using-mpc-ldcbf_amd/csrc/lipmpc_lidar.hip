@@ -345,14 +345,22 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
         : "+v"(lo), "+v"(hi), "=&s"(keep)
         : "s"((int)(unsigned)mask), "s"((int)(unsigned)(mask >> 32)), "s"(l));
   };
+  // Only the blocks w >= k are computed: in a block with w > k every lane also notes, per column, whether ITS point (of
+  // word w) is within eps of the column's point (of word k) -- bit kk of its own row[w][k], the transposed block, for
+  // two more instructions per column instead of a second pass.
   for (int k = 0; k < NW; ++k) {                          // wave-uniform
     unsigned nmk[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) nmk[a] = __builtin_amdgcn_readfirstlane(nearm_[k * 4 + a]);
+    const int leftk = n_pts - k * 64;
+    const unsigned long long vmk = leftk >= 64 ? ~0ull : ((1ull << leftk) - 1ull);        // vmask[k] (leftk >= 1 for k < NW)
+    const bool own_k = (vmk >> lane) & 1ull;
 #pragma unroll
     for (int w = 0; w < WORDS; ++w) {
-      if (w >= NW) continue;
+      if (w >= NW || w < k) continue;
+      const bool off = w != k;                            // wave-uniform: an off-diagonal block also fills its transpose
       int lo = 0, hi = 0;                                 // the row words being assembled: lane kk gets the mask of column kk
+      unsigned tlo = 0u, thi = 0u;                        // this lane's point (word w) against the columns (word k)
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         if (((nmk[a] >> (4 * w)) & 0xFu) == 0u) continue; // run a of word k has no point near word w
@@ -361,13 +369,26 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
         for (int u = 0; u < 16; ++u) {
 #pragma clang fp contract(off)
           const double dx = wxr[w] - col[2 * u], dy = wyr[w] - col[2 * u + 1];
-          const unsigned long long mask = __ballot(dx * dx + dy * dy <= eps2);
+          const bool near = dx * dx + dy * dy <= eps2;
+          const unsigned long long mask = __ballot(near);
           wrlane64(lo, hi, mask, a * 16 + u);
+          if (off) {
+            constexpr unsigned one = 1u;
+            if (a < 2) tlo |= near ? (one << ((a * 16 + u) & 31)) : 0u;
+            else thi |= near ? (one << ((a * 16 + u) & 31)) : 0u;
+          }
         }
       }
       const unsigned long long bits = ((((unsigned long long)(unsigned)hi) << 32) | (unsigned)lo) & vmask[w];
+      const unsigned long long tbits = ((((unsigned long long)thi) << 32) | tlo) & vmk;
+      const bool own_w = (vmask[w] >> lane) & 1ull;
 #pragma unroll
-      for (int k2 = 0; k2 < WORDS; ++k2) if (k2 == k) row[k2][w] = ((vmask[k2] >> lane) & 1ull) ? bits : 0ull;     // k is wave-uniform
+      for (int k2 = 0; k2 < WORDS; ++k2) {
+        if (k2 == k) {                                     // k is wave-uniform
+          row[k2][w] = own_k ? bits : 0ull;
+          if (off) row[w][k2] = own_w ? tbits : 0ull;
+        }
+      }
     }
   }
   // core points (>= min_samples neighbours, the point itself included) start as their own root
