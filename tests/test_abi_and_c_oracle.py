@@ -60,6 +60,13 @@ def test_default_params_are_the_reference_config():
     assert lib.lipmpc_num_rows(C.byref(q)) == d.num_rows == 27
     q.N, q.n_obs_max = 8, 10
     assert lib.lipmpc_num_rows(C.byref(q)) == 162 and lib.lipmpc_active_words(C.byref(q)) == 3
+    # schedule buffer of the LiDAR front end: header + start order + reading counts (include/lipmpc.h)
+    assert lib.lipmpc_lidar_schedule_words(4096) == 2 + 2 * 4096 and lib.lipmpc_lidar_schedule_words(0) == 2
+    assert lib.lipmpc_lidar_schedule_words(-1) < 0
+    # argument errors of the LiDAR entry points never reach a device (no GPU needed)
+    z = C.c_void_p(0)
+    assert lib.lipmpc_lidar_c_eta_batch(0, 1, 360, 0, 1, 1, C.c_double(1.5), C.c_double(0.3), 3, 12, 32, *([z] * 14)) == -1   # no c_eta
+    assert lib.lipmpc_sense_plan_step_batch(z, 1, 360, 0, 1, 1, C.c_double(1.5), C.c_double(0.3), 3, *([z] * 23)) == -1       # no handle
 
 
 def test_create_without_gpu_fails_cleanly():
