@@ -106,6 +106,11 @@ def main():
     goal_xy = (10.0, 10.0) if N <= 8 else (16.0, 16.0)
     P = lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5, finish_rounds=args.finish_rounds)
     solver = lipmpc.BatchedLipMpc(P, local_rank)
+    # more problems than the GPU holds at once (4096 at N <= 8): consecutive steps of one batch run on a cost-ordered
+    # schedule (lipmpc_set_schedule: costliest first, like with like, by the previous launch's iteration counts)
+    scheduled = B > 4096 and os.environ.get("LIPMPC_BENCH_NO_SCHEDULE") != "1"
+    if scheduled:
+        solver.set_schedule(B)
     walker = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5, flags=lipmpc.FLAG_INTERIOR), local_rank)
 
     # ---- synthetic inputs (seeded per rank), placed in HBM before the timed region -------------
@@ -191,7 +196,8 @@ def main():
             "config": {"workload": f"{cfg_name}: {total} robots in all ({B} on rank 0), N={N}, {n_obs} convex-polygon obstacles "
                                    "(generate_obstacles distribution), states from closed-loop warm-up, delta in {0,0.3}",
                        "total_batch": total, "batch_rank0": B, "horizon": N, "obstacles": n_obs,
-                       "parallelism": f"contiguous batch shards x{world}, no data-path collective"},
+                       "parallelism": f"contiguous batch shards x{world}, no data-path collective",
+                       "launch_order": "cost-ordered schedule from the previous step (lipmpc_set_schedule)" if scheduled else "index order"},
             "solver": {"mean_iters": float(iters.mean()), "max_iters": int(iters.max()),
                        "status_hist": {str(k): int(v) for k, v in zip(*np.unique(status, return_counts=True))},
                        "solved_frac": n_ok / B},

@@ -21,7 +21,7 @@ class LipmpcParamsC(C.Structure):
 
 
 EXPORTS = ("lipmpc_default_params", "lipmpc_create", "lipmpc_destroy", "lipmpc_num_rows",
-           "lipmpc_active_words", "lipmpc_plan_step_batch", "lipmpc_plan_step_batch_c_eta", "lipmpc_advance_batch", "lipmpc_fleet_update_batch", "lipmpc_rollout_batch", "lipmpc_lidar_sense_batch", "lipmpc_lidar_c_eta_batch", "lipmpc_lidar_schedule_words", "lipmpc_sense_plan_step_batch",
+           "lipmpc_active_words", "lipmpc_plan_step_batch", "lipmpc_plan_step_batch_c_eta", "lipmpc_advance_batch", "lipmpc_fleet_update_batch", "lipmpc_rollout_batch", "lipmpc_lidar_sense_batch", "lipmpc_lidar_c_eta_batch", "lipmpc_lidar_schedule_words", "lipmpc_sense_plan_step_batch", "lipmpc_set_schedule", "lipmpc_schedule_words",
            "lipmpc_strerror", "lipmpc_version")
 
 _lib = None
@@ -68,6 +68,10 @@ def load():
     lib.lipmpc_lidar_schedule_words.restype = i64
     lib.lipmpc_sense_plan_step_batch.argtypes = ([vp, i64] + [C.c_int32] * 4 + [C.c_double, C.c_double, C.c_int32] + [vp] * 23)
     lib.lipmpc_sense_plan_step_batch.restype = i32
+    lib.lipmpc_set_schedule.argtypes = [vp, vp, i64]
+    lib.lipmpc_set_schedule.restype = i32
+    lib.lipmpc_schedule_words.argtypes = [i64]
+    lib.lipmpc_schedule_words.restype = i64
     lib.lipmpc_strerror.argtypes = [i32]
     lib.lipmpc_strerror.restype = C.c_char_p
     lib.lipmpc_version.argtypes = []

@@ -66,6 +66,26 @@ __global__ void fleet_update_kernel(long B, int k_max, double stop_obj, double c
 }
 __global__ void fleet_next_sample_kernel(int32_t* sample) { *sample += 1; }
 
+// The order of the NEXT step launch on a schedule from the costs this launch left: problems by descending cost (counting
+// sort, one workgroup; which of two equally costly problems comes first is immaterial).
+__global__ __launch_bounds__(1024) void order_by_cost_kernel(long B, int32_t* __restrict__ sched) {
+  __shared__ int cursor_[SCHED_COST_BINS];
+  const int32_t* w = sched + SCHED_ORDER + B;
+  int32_t* order = sched + SCHED_ORDER;
+  for (int k = threadIdx.x; k < SCHED_COST_BINS; k += blockDim.x) cursor_[k] = 0;
+  __syncthreads();
+  for (long i = threadIdx.x; i < B; i += blockDim.x) atomicAdd(&cursor_[SCHED_COST_BINS - 1 - min(max(w[i], 0), SCHED_COST_BINS - 1)], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int k = 0; k < SCHED_COST_BINS; ++k) { const int c = cursor_[k]; cursor_[k] = run; run += c; }
+  }
+  __syncthreads();
+  for (long i = threadIdx.x; i < B; i += blockDim.x)
+    order[atomicAdd(&cursor_[SCHED_COST_BINS - 1 - min(max(w[i], 0), SCHED_COST_BINS - 1)], 1)] = (int32_t)i;
+  if (threadIdx.x == 0) sched[SCHED_VALID] = (int32_t)B;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -78,6 +98,8 @@ struct lipmpc_handle {
   int G;
   int nobs_l;
   int nvar;     // variable slots of the factorisation: G, or 8 (horizons up to 4, register-row instantiations)
+  int32_t* sched;       // optional schedule buffer (lipmpc_set_schedule), device memory owned by the caller
+  int64_t sched_cap;    // largest batch it holds
 };
 
 extern "C" {
@@ -130,7 +152,7 @@ void lipmpc_destroy(lipmpc_handle* h) { free(h); }
 
 #define LAUNCH(GG, NL, NV)                                                                                     \
   launch_plan_step<GG, NL, NV>(h->k, (long)B, state, goal, first_foot, delta, obs_xy, obs_nv, U, X, theta, omega, obj, \
-                               status, iters, (unsigned long long*)active, c_eta, diag, bounds, c_eta_in, stream)
+                               status, iters, (unsigned long long*)active, c_eta, diag, bounds, c_eta_in, sched, stream)
 
 static int plan_step_impl(lipmpc_handle* h, int64_t B, const double* state, const double* goal,
                           const int8_t* first_foot, const double* delta, const double* obs_xy,
@@ -144,6 +166,7 @@ static int plan_step_impl(lipmpc_handle* h, int64_t B, const double* state, cons
   if (h->p.n_obs_max > 0 && !c_eta_in && (!obs_xy || !obs_nv)) return LIPMPC_E_ARG;
   if (hipSetDevice(h->device) != hipSuccess) return LIPMPC_E_HIP;
   hipStream_t stream = (hipStream_t)hip_stream;
+  int32_t* sched = (h->sched && B <= h->sched_cap) ? h->sched : nullptr;
   if (h->G == 16 && h->nvar == 8) {
     switch (h->nobs_l) {
       case 0: LAUNCH(16, 0, 8); break;
@@ -170,8 +193,18 @@ static int plan_step_impl(lipmpc_handle* h, int64_t B, const double* state, cons
       default: LAUNCH(32, 25, 32); break;
     }
   }
+  if (sched) hipLaunchKernelGGL(order_by_cost_kernel, dim3(1), dim3(1024), 0, stream, (long)B, sched);
   return hipGetLastError() == hipSuccess ? LIPMPC_OK : LIPMPC_E_HIP;
 }
+
+int lipmpc_set_schedule(lipmpc_handle* h, int32_t* schedule, int64_t capacity) {
+  if (!h || capacity < 0 || (schedule && capacity > 0x3fffffff)) return LIPMPC_E_ARG;
+  h->sched = capacity > 0 ? schedule : nullptr;
+  h->sched_cap = h->sched ? capacity : 0;
+  return LIPMPC_OK;
+}
+
+int64_t lipmpc_schedule_words(int64_t B) { return B < 0 ? LIPMPC_E_ARG : SCHED_ORDER + 2L * B; }
 
 int lipmpc_plan_step_batch(lipmpc_handle* h, int64_t B, const double* state, const double* goal,
                            const int8_t* first_foot, const double* delta, const double* obs_xy,

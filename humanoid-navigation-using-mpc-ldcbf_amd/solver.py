@@ -81,6 +81,16 @@ class BatchedLipMpc:
         cp = params.to_c()
         _lib.check(self.lib.lipmpc_create(C.byref(cp), self.device_index, C.byref(self._h)), "lipmpc_create")
 
+    def set_schedule(self, capacity):
+        """Launch order for this handle's step solves (lipmpc_set_schedule): every plan_step_batch / plan_step_batch_c_eta of
+        at most ``capacity`` problems leaves each problem's cost and the order -- costliest first, like with like -- the
+        next launch of the same batch size places them in.  Pays off beyond the 4096 problems the GPU holds at once,
+        when consecutive launches see the same or slowly moving problems; results never depend on it.  0 = off."""
+        capacity = int(capacity)
+        self._sched = (torch.zeros((int(self.lib.lipmpc_schedule_words(capacity)),), dtype=torch.int32, device=self.device)
+                       if capacity > 0 else None)
+        _lib.check(self.lib.lipmpc_set_schedule(self._h, _ptr(self._sched), capacity), "lipmpc_set_schedule")
+
     def __del__(self):
         h = getattr(self, "_h", None)
         if h is not None and h.value:

@@ -123,6 +123,18 @@ int lipmpc_plan_step_batch(lipmpc_handle* h, int64_t B,
                            int32_t* status, int32_t* iters, uint64_t* active, double* c_eta, double* diag,
                            const double* bounds, void* hip_stream);
 
+/* Optional launch order for the step solves of a handle.  A wave lasts as long as the slowest of its problems and a launch
+ * of more problems than the GPU holds at once (4096 at N <= 8) runs in rounds, so WHICH problems share a wave and which start
+ * first matters: with a schedule every lipmpc_plan_step_batch / _c_eta launch of at most `capacity` problems leaves there each
+ * problem's cost (interior-point iterations + finish rounds) and (one small extra kernel) the order -- costliest first,
+ * like with like -- in which the next launch of the same batch size places them (+12 % throughput at 32768 problems when
+ * consecutive launches see the same or slowly moving problems, as the samples of a closed loop do).  A pure scheduling
+ * hint: outputs stay indexed by problem, every order gives the same results, a buffer holding no order for this B means
+ * index order.  `schedule`: device buffer of lipmpc_schedule_words(capacity) int32, zeroed once by the caller, owned by the
+ * caller and alive until it is unset (NULL) or the handle destroyed; launches on it must be stream-ordered. */
+int lipmpc_set_schedule(lipmpc_handle* h, int32_t* schedule, int64_t capacity);
+int64_t lipmpc_schedule_words(int64_t B);
+
 /* The same step with the LDCBF half-spaces GIVEN instead of derived from obstacle rings: the reference's subclass
  * hooks HumanoidMPC._get_list_c_and_eta(x_k, y_k) -> (list_c, list_eta) (HumanoidMpc.py:296-319; overridden by
  * HumanoidMPCUnknownEnvironment.py:30-68) and _compute_single_lcbf(x, eta, c) (HumanoidMpc.py:252-261; overridden by

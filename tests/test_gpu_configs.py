@@ -242,6 +242,38 @@ def test_config3_batch_32768():
             assert np.array_equal(o["active"].cpu().numpy(), g["active"][lo:hi])
 
 
+def test_cost_ordered_schedule_changes_nothing_but_the_order():
+    """lipmpc_set_schedule: launches on a schedule place the problems by the previous launch's costs (costliest first, like
+    with like).  Outputs stay indexed by problem and are bit-identical to the unscheduled launch, launch after launch,
+    also across a change of batch size; the order the buffer holds is a permutation sorted by descending cost."""
+    B, N, n_obs = 8192, 8, 10
+    b = _walked_batch(B, N, n_obs, 9.5, (10.0, 10.0), seed=5, max_steps=30, n_fields=2048, delta_mix=True)
+    P = lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5)
+    args = (b["state"], b["goal"], b["foot"], b["obs_xy"], b["obs_nv"], b["delta"])
+    ref = lipmpc.BatchedLipMpc(P).plan_step_batch(*args, with_diag=True)
+    sv = lipmpc.BatchedLipMpc(P)
+    sv.set_schedule(B)
+    for rep in range(3):
+        got = sv.plan_step_batch(*args, with_diag=True)
+        torch.cuda.synchronize()
+        for k in ("status", "iters", "active", "theta", "omega"):
+            assert torch.equal(got[k], ref[k]), (rep, k)
+        for k in ("U", "X", "obj", "diag"):
+            assert torch.equal(torch.nan_to_num(got[k], nan=7.0), torch.nan_to_num(ref[k], nan=7.0)), (rep, k)
+        sc = sv._sched.cpu().numpy()
+        order, cost = sc[2:2 + B], sc[2 + B:]
+        assert sc[0] == B and np.array_equal(np.sort(order), np.arange(B)) and np.all(np.diff(cost[order]) <= 0)
+        assert np.array_equal(cost, np.minimum(127, ref["iters"].cpu().numpy() + 2 * ref["diag"][:, 0].cpu().numpy().astype(int)))
+    half = tuple(t[: B // 2].contiguous() for t in args)               # another batch size on the same schedule: index order, same answers
+    got = sv.plan_step_batch(*half)
+    torch.cuda.synchronize()
+    assert torch.equal(got["iters"], ref["iters"][: B // 2]) and torch.equal(torch.nan_to_num(got["U"], nan=7.0), torch.nan_to_num(ref["U"][: B // 2], nan=7.0))
+    sv.set_schedule(0)
+    got = sv.plan_step_batch(*args)
+    torch.cuda.synchronize()
+    assert torch.equal(got["iters"], ref["iters"])
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # config 4
 # ---------------------------------------------------------------------------------------------------------------
