@@ -170,6 +170,8 @@ class BatchedLipMpc:
         self._check_optional(bounds, (B, 4), torch.float64, "bounds")
         if out is None:
             out = self.alloc_outputs(B, False, with_diag)
+        else:
+            self._check_outputs(out, B)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = self.lib.lipmpc_plan_step_batch_c_eta(
             self._h, B, _ptr(state), _ptr(goal), _ptr(first_foot), _ptr(delta), _ptr(c_eta_in),
@@ -200,6 +202,9 @@ class BatchedLipMpc:
         """In place: state <- (A_l x + B_l U[:,0], theta[:,1]), first_foot <- -first_foot for the
         problems whose status is solved (HumanoidMpc.py:432-447)."""
         B = state.shape[0]
+        self._check_optional(state, (B, 5), torch.float64, "state")
+        self._check_optional(first_foot, (B,), torch.int8, "first_foot")
+        self._check_outputs(out, B)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = self.lib.lipmpc_advance_batch(self._h, B, _ptr(state), _ptr(first_foot), _ptr(out["U"]),
                                            _ptr(out["theta"]), _ptr(out["status"]), C.c_void_p(stream))
@@ -213,6 +218,15 @@ class BatchedLipMpc:
         n_overflow, sample int32[1], X_pred [B,k_max+1,5], U_pred [B,k_max,3]); the device-side sample counter
         advances by one per call."""
         B, k_max = fleet["state"].shape[0], fleet["U_pred"].shape[1]
+        for name, shape, dt in (("state", (B, 5), torch.float64), ("first_foot", (B,), torch.int8), ("walking", (B,), torch.int8),
+                                ("last_obj", (B,), torch.float64), ("n_steps", (B,), torch.int32), ("last_status", (B,), torch.int32),
+                                ("n_overflow", (B,), torch.int32), ("sample", (1,), torch.int32),
+                                ("X_pred", (B, k_max + 1, 5), torch.float64), ("U_pred", (B, k_max, 3), torch.float64)):
+            if name not in fleet:
+                raise ValueError(f"fleet['{name}'] missing")
+            self._check_optional(fleet[name], shape, dt, f"fleet['{name}']")
+        self._check_outputs(out, B)
+        self._check_optional(overflow, (B,), torch.int32, "overflow")
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = self.lib.lipmpc_fleet_update_batch(
             self._h, B, int(k_max), float(stop_obj), _ptr(fleet["state"]), _ptr(fleet["first_foot"]), _ptr(fleet["walking"]),
@@ -226,6 +240,9 @@ class BatchedLipMpc:
         """Closed loop on the device (HumanoidMpc.py:345-459) for B robots: returns dict(X_pred [B,k_max+1,5],
         U_pred [B,k_max,3], n_steps [B], last_status [B], total_iters [B]); rows beyond n_steps are undefined."""
         B = self._check_inputs(state0, goal, first_foot, obs_xy, obs_nv, delta)
+        self._check_optional(bounds, (B, 4), torch.float64, "bounds")
+        if int(k_max) < 1 or int(mpc_step) < 1:
+            raise ValueError("k_max and mpc_step must be positive")
         dev = self.device
         out = dict(X_pred=torch.empty((B, k_max + 1, 5), dtype=torch.float64, device=dev),
                    U_pred=torch.empty((B, k_max, 3), dtype=torch.float64, device=dev),
