@@ -16,8 +16,10 @@ Outputs (data only):
                       coordinates with the affine map of HumanoidMPCWithRRT._build_occupancy_grid, :44-64).
 Runs: Simulation1 (simulation_1.py:33-50, BASE seed 7), Simulation1Circles (:85-102), Simulation1CirclesDelta (:146-160),
 SimulationRRT-NoRRT (simulation_rrt.py:17-45), SimulationRRT (:67-84), SimulationMaze1 / SimulationMaze2
-(simulation_maze.py:14-60 with MAZE_1 -> (7.5, 7.5) and MAZE_2 -> (0.5, 7.5)).  The four *UnkEnv runs used unseeded
-sensor noise (range_finder_wth_polygons_dbscan.py:162-172) and cannot be reproduced.
+(simulation_maze.py:14-60 with MAZE_1 -> (7.5, 7.5) and MAZE_2 -> (0.5, 7.5)), Simulation4UnkEnv (simulation_1.py:195-232,
+the unknown-environment run as committed: its map and start are reproducible, its sensor noise -- unseeded,
+range_finder_wth_polygons_dbscan.py:162-172 -- is not, so it pins the closed loop to the centimetres sigma = 0.01 m of
+noise leaves).  Simulation1..3UnkEnv start at theta = pi/4: produced by variants of the script that are not committed.
 """
 import math
 import os
@@ -87,7 +89,7 @@ def main():
     series = {}
     runs = [("Simulation1", "evolutions"), ("Simulation1Circles", "evolutions"), ("Simulation1CirclesDelta", "evolutions"),
             ("SimulationRRT-NoRRT", "evolutions"), ("SimulationRRT", "evolutions"), ("SimulationMaze1", "evolutions.pdf"),
-            ("SimulationMaze2", "evolutions")]
+            ("SimulationMaze2", "evolutions"), ("Simulation4UnkEnv", "evolutions")]
     for run, sub in runs:
         for i in range(6):
             p = f"{ROOT}/{run}/{sub}/evolution_{i}.pdf"
@@ -122,6 +124,21 @@ def main():
     put("SimulationMaze1", m1, (0, 0, 0, 0, 0), g1, 3, subgoals=rrt_subgoals(f"{ROOT}/SimulationMaze1/rrt_res.pdf", m1, g1))
     _, g2, m2 = Scenario.load_scenario(Scenario.MAZE_2, (0.5, 0.5), (0.5, 7.5), 20, range_x=(-1, 6), range_y=(-1, 6))
     put("SimulationMaze2", m2, (0, 0, 0, 0, 0), g2, 3, subgoals=rrt_subgoals(f"{ROOT}/SimulationMaze2/rrt_res.pdf", m2, g2))
+    # Simulation4UnkEnv = run_simulation_unk_env as committed (simulation_1.py:195-232): CROWDED map of 20 obstacles in
+    # (-1, 6)^2 under seed 10, start (0, 0, pi/2), goal (4, 3.5), N = 3, lidar_range 1.5.  The sensor noise was unseeded
+    # (range_finder_wth_polygons_dbscan.py:162-172), so the figure pins the closed loop only as far as sigma = 0.01 m of
+    # sensor noise lets it: the map is stored as the raw `ch.points` arrays the reference scans (:46), in list order.
+    from HumanoidNavigation.Utils.ObstaclesUtils import ObstaclesUtils
+    from HumanoidNavigation.Utils.obstacles import set_seed
+    ObstaclesUtils.set_random_seed(10); set_seed(10)
+    _, g4, crowd = Scenario.load_scenario(Scenario.CROWDED, (0, 0), (4, 3.5), 20, range_x=(-1, 6), range_y=(-1, 6))
+    put("Simulation4UnkEnv", crowd, (0, 0, 0, 0, math.pi / 2), g4, 3)
+    vmax = max(len(h.points) for h in crowd)
+    pts = np.zeros((len(crowd), vmax, 2)); npt = np.zeros(len(crowd), np.int32)
+    for i, h in enumerate(crowd):
+        pts[i, :len(h.points)] = np.asarray(h.points, float); npt[i] = len(h.points)
+    sc["Simulation4UnkEnv/env_pts"] = pts; sc["Simulation4UnkEnv/env_n"] = npt
+    sc["Simulation4UnkEnv/lidar_range"] = np.float64(1.5)
     np.savez_compressed(os.path.join(HERE, "pdf_scenarios.npz"), **sc)
 
 

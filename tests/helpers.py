@@ -1,4 +1,6 @@
 """Shared test helpers (CPU side)."""
+import math
+
 import numpy as np
 
 import lipmpc_oracle as O
@@ -83,6 +85,8 @@ PDF_BARS = {
     "SimulationRRT": (2e-6, 1e-7, 1e-5, 20, None),            # 11 sub-goals: the chained loop is chaotic after ~30 steps
     "SimulationMaze1": (5e-6, 5e-7, 1e-3, 3, None),
     "SimulationMaze2": (5e-6, 5e-7, 1e-3, 3, 0.05),
+    # unknown environment: the reference's sensor noise (sigma = 0.01 m per reading, unseeded) is part of its figure
+    "Simulation4UnkEnv": (5e-6, 1e-7, 2e-3, 2, 0.12),
 }
 
 
@@ -144,3 +148,40 @@ def check_pdf_bars(run, X, cmp):
     assert abs(X.shape[1] - cmp["n_ref"]) <= nslack, (run, X.shape[1], cmp["n_ref"])
     if pall is not None:
         assert cmp["pos_all"] <= pall, (run, cmp)
+
+
+def unknown_env_scenario(golden_dir, run="Simulation4UnkEnv"):
+    """The committed unknown-environment run (simulation_1.py:195-232): the true map as the raw point arrays the reference
+    scans, init state, goal, horizon, LiDAR range."""
+    import os
+    S = np.load(os.path.join(golden_dir, "pdf_scenarios.npz"))
+    env = [S[run + "/env_pts"][i][: S[run + "/env_n"][i]] for i in range(len(S[run + "/env_n"]))]
+    return dict(env=env, init=tuple(S[run + "/init"]), goal=tuple(S[run + "/goal"]), N=int(S[run + "/N"]),
+                lidar_range=float(S[run + "/lidar_range"]))
+
+
+def oracle_unknown_env_run(golden_dir, noise_seed, run="Simulation4UnkEnv", k_max=300, tol=IPOPT_LIKE_TOL):
+    """Closed loop of HumanoidMPCUnknownEnvironment on the oracle chain: per step lidar oracle (scan, noise, DBSCAN, hulls)
+    -> step oracle (interior mode) -> advance; HumanoidMpc.py:380-459 with _get_list_c_and_eta from
+    HumanoidMPCUnknownEnvironment.py:30-68.  noise_seed None = noiseless readings."""
+    import lidar_oracle as L
+    sc = unknown_env_scenario(golden_dir, run)
+    P = O.Params(N=sc["N"], tol_interior=tol, sampling_time=0.4)
+    A, B = O.lip_matrices(P)
+    rng = np.random.default_rng(noise_seed) if noise_seed is not None else None
+    tab = L.ray_table()
+    st = np.array(sc["init"], float)
+    X, U, last = [st.copy()], [], math.inf
+    for k in range(k_max):
+        if last < 0.05:                                                        # HumanoidMpc.py:392
+            break
+        noise = None if rng is None else L.NOISE_STD * rng.standard_normal((len(tab), 2))
+        _, _, _, inferred = L.range_finder((st[0], st[2]), sc["env"], sc["lidar_range"], noise=noise, table=tab)
+        r = O.plan_step(st, sc["goal"], 1 if k % 2 == 0 else -1, inferred, 0.0, P, exact=False)
+        if r["status"] not in (O.STATUS_SOLVED, O.STATUS_UNCERTIFIED):
+            break
+        last = r["obj"]
+        U.append([r["U"][0][0], r["U"][0][1], r["omega"][0]])
+        st = np.concatenate([A @ st[:4] + B @ r["U"][0], [r["theta"][1]]])
+        X.append(st.copy())
+    return np.array(X).T, np.array(U).T

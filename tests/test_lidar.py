@@ -55,6 +55,40 @@ def test_hull_rules():
     assert np.array_equal(r, np.array([[0.0, 0], [2, 0], [2, 2], [0, 2]]))          # CCW, edge midpoint dropped
 
 
+@pytest.mark.parametrize("noise_seed", [0, 3])
+def test_unknown_environment_closed_loop_against_the_reference_figure(golden_dir, noise_seed):
+    """BASELINE config 5 end to end against the reference's own output: the unknown-environment run the reference commits
+    (Assets/ReportResults/Simulation4UnkEnv, produced by simulation_1.py:195-232: CROWDED map under seed 10, start
+    (0, 0, pi/2), goal (4, 3.5), N = 3, lidar_range 1.5) on the oracle chain lidar oracle -> step oracle.  The reference's
+    sensor noise was unseeded, so the figure pins the loop as far as sigma = 0.01 m of noise lets it -- which is: the same
+    run length (57 states), the first steps to 1e-7, ten steps to 0.5 mm, the whole run to 4 cm, for any noise sample."""
+    from helpers import check_pdf_bars, oracle_unknown_env_run, pdf_compare
+    X, U = oracle_unknown_env_run(golden_dir, noise_seed)
+    cmp = pdf_compare(golden_dir, "Simulation4UnkEnv", X, U)
+    print("Simulation4UnkEnv, oracle chain, noise seed", noise_seed, X.shape[1], cmp)
+    check_pdf_bars("Simulation4UnkEnv", X, cmp)
+    assert np.hypot(X[0, -1] - 4.0, X[2, -1] - 3.5) < 0.1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("noise_seed", [0, 1])
+def test_gpu_unknown_environment_class_against_the_reference_figure(golden_dir, noise_seed):
+    """The same pin through the GPU drop-in class lipmpc.HumanoidMPCUnknownEnvironment (scan + constraint assembly in one
+    launch per sample, then the solve): the reference's committed unknown-environment figure, same bars as the oracle chain."""
+    pytest.importorskip("torch")
+    import lipmpc
+    from helpers import check_pdf_bars, pdf_compare, unknown_env_scenario
+    sc = unknown_env_scenario(golden_dir)
+    mpc = lipmpc.HumanoidMPCUnknownEnvironment(goal=sc["goal"], obstacles=sc["env"], N_horizon=sc["N"], N_mpc_timesteps=300,
+                                               sampling_time=0.4, init_state=sc["init"], verbosity=0,
+                                               lidar_range=sc["lidar_range"], noise_seed=noise_seed)
+    X, U, _ = mpc.run_simulation(None, make_fast_plot=False, fill_animator=False)
+    cmp = pdf_compare(golden_dir, "Simulation4UnkEnv", X, U)
+    print("Simulation4UnkEnv, GPU class, noise seed", noise_seed, X.shape[1], cmp)
+    check_pdf_bars("Simulation4UnkEnv", X, cmp)
+    assert np.hypot(X[0, -1] - 4.0, X[2, -1] - 3.5) < 0.1
+
+
 @pytest.mark.gpu
 def test_gpu_lidar_matches_reference_and_oracle(golden_dir):
     torch = pytest.importorskip("torch")
