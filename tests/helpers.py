@@ -90,6 +90,19 @@ PDF_BARS = {
 }
 
 
+# run -> bars on the other panels of the figures: velocities in the robot frame (first steps k <= 2, k <= 10) and the FOOTSTEPS
+# (ZMP x = U_pred[0, k]) where the figure shows them: (k <= 10, whole window); None = panel absent / not comparable
+PDF_BARS_EXTRA = {
+    "Simulation1Circles": (2e-6, 3e-3, 2e-3, 0.05),
+    "Simulation1CirclesDelta": (2e-6, 5e-3, 3e-3, 0.05),
+    "SimulationRRT-NoRRT": (2e-3, 0.06, None, None),
+    "SimulationRRT": (5e-6, 2e-5, None, 0.02),           # its footstep window starts at step 23
+    "SimulationMaze1": (None, None, None, None),          # the velocity panel of this run is not on the 0.4 s grid of the others
+    "SimulationMaze2": (5e-6, 1e-3, None, None),          # its CoM / ZMP panel holds four curves
+    "Simulation4UnkEnv": (2e-6, 5e-3, 2e-3, 0.05),
+}
+
+
 def pdf_scenario(golden_dir, run):
     import os
     S = np.load(os.path.join(golden_dir, "pdf_scenarios.npz"))
@@ -122,6 +135,27 @@ def pdf_compare(golden_dir, run, X, U):
         kk = k[ok]
         for w, lim in (("k2", 2), ("k10", 10), ("all", 10 ** 9)):
             out[name + "_" + w] = max(out.get(name + "_" + w, 0.0), float(d[kk <= lim].max()))
+    # the other panels of the figures: translational velocities in the robot frame (PlotsUtils.compute_local_velocities:
+    # [[cos, sin], [-sin, cos]] (v_x, v_y) at the state's heading) and, where the panel holds exactly (CoM x, ZMP x), the
+    # FOOTSTEPS themselves: ZMP x = U_pred[0, k] over the window the scripts zoom into (clipped end points are dropped)
+    th = X[4]
+    extra = [("vel", np.cos(th) * X[1] + np.sin(th) * X[3], "/ev1/s0"), ("vel", -np.sin(th) * X[1] + np.cos(th) * X[3], "/ev1/s1")]
+    if run + "/ev4/s1" in P.files and run + "/ev4/s2" not in P.files:
+        extra += [("zmp", U[0], "/ev4/s1")]
+    for name, src, key in extra:
+        if run + key not in P.files:
+            continue
+        s = P[run + key]
+        on_grid = np.abs(s[:, 0] / 0.4 - np.round(s[:, 0] / 0.4)) < 1e-4
+        k = np.round(s[on_grid, 0] / 0.4).astype(int)
+        v = s[on_grid, 1]
+        ok = k < len(src)
+        d, kk = np.abs(src[k[ok]] - v[ok]), k[ok]
+        for w, lim in (("k2", 2), ("k10", 10), ("all", 10 ** 9)):
+            if np.any(kk <= lim):
+                out[name + "_" + w] = max(out.get(name + "_" + w, 0.0), float(d[kk <= lim].max()))
+        if name == "zmp":
+            out["zmp_first_k"], out["zmp_n"] = int(kk.min()), int(len(kk))
     out["n_ref"] = n_ref
     return out
 
@@ -148,6 +182,10 @@ def check_pdf_bars(run, X, cmp):
     assert abs(X.shape[1] - cmp["n_ref"]) <= nslack, (run, X.shape[1], cmp["n_ref"])
     if pall is not None:
         assert cmp["pos_all"] <= pall, (run, cmp)
+    v2, v10, z10, zall = PDF_BARS_EXTRA[run]
+    for key, bar in (("vel_k2", v2), ("vel_k10", v10), ("zmp_k10", z10), ("zmp_all", zall)):
+        if bar is not None:
+            assert key in cmp and cmp[key] <= bar, (run, key, cmp.get(key), bar)
 
 
 def unknown_env_scenario(golden_dir, run="Simulation4UnkEnv"):
