@@ -97,7 +97,7 @@ PDF_BARS_EXTRA = {
     "Simulation1CirclesDelta": (2e-6, 5e-3, 3e-3, 0.05),
     "SimulationRRT-NoRRT": (2e-3, 0.06, None, None),
     "SimulationRRT": (5e-6, 2e-5, None, 0.02),           # its footstep window starts at step 23
-    "SimulationMaze1": (None, None, None, None),          # the velocity panel of this run is not on the 0.4 s grid of the others
+    "SimulationMaze1": (5e-5, 5e-3, None, None),
     "SimulationMaze2": (5e-6, 1e-3, None, None),          # its CoM / ZMP panel holds four curves
     "Simulation4UnkEnv": (2e-6, 5e-3, 2e-3, 0.05),
 }
@@ -140,6 +140,8 @@ def pdf_compare(golden_dir, run, X, U):
     # FOOTSTEPS themselves: ZMP x = U_pred[0, k] over the window the scripts zoom into (clipped end points are dropped)
     th = X[4]
     extra = [("vel", np.cos(th) * X[1] + np.sin(th) * X[3], "/ev1/s0"), ("vel", -np.sin(th) * X[1] + np.cos(th) * X[3], "/ev1/s1")]
+    if run == "SimulationMaze1":          # this figure shows the GLOBAL velocities, as simulation_maze.py:62 plots them
+        extra = [("vel", X[1], "/ev1/s0"), ("vel", X[3], "/ev1/s1")]
     if run + "/ev4/s1" in P.files and run + "/ev4/s2" not in P.files:
         extra += [("zmp", U[0], "/ev4/s1")]
     for name, src, key in extra:
