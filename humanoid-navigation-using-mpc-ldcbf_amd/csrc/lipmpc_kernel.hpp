@@ -9,10 +9,12 @@
 //   LDCBF rows of stage a+1: obstacle j on lane c = j & 1.
 // Rows are generated, never stored: G q, G^T w and K = 2I + G^T D G are applied through the
 // problem's structure (rotation blocks, the alternating-sum velocity map, per-stage 2x2 LDCBF
-// blocks), so a problem's live state is n + ~2.5 m doubles in registers.  For large obstacle sets
-// (more than 5 LDCBF rows per lane) those rows are STREAMED instead: (s, z) per row in LDS, everything
-// else recomputed in each pass (step_body, STREAM).  Two kernels share the body: plan_step_kernel
-// (one step for B problems) and rollout_kernel (the whole closed loop per robot, one launch).
+// blocks), so a problem's live state is n + ~3 m doubles in registers.  For large obstacle sets
+// (more than 7 LDCBF rows per lane) those rows are STREAMED instead: (s, z) per row in LDS, everything
+// else recomputed in each pass (step_body, STREAM).  Horizons up to 4 run the factorisation on 8 variable
+// slots (NVAR = 8).  Two kernels share the body: plan_step_kernel (one step for B problems, optionally in the
+// cost order of the previous launch: lipmpc_set_schedule) and rollout_kernel (the whole closed loop per
+// robot, one launch).
 //
 // Reference semantics followed (HumanoidNavigation/...):
 //   theta/omega            MPC/HumanoidMpc.py:137-160
