@@ -106,9 +106,10 @@ def main():
     goal_xy = (10.0, 10.0) if N <= 8 else (16.0, 16.0)
     P = lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5, finish_rounds=args.finish_rounds)
     solver = lipmpc.BatchedLipMpc(P, local_rank)
-    # more problems than the GPU holds at once (4096 at N <= 8): consecutive steps of one batch run on a cost-ordered
+    # more problems than the GPU holds at once (4096 at N <= 8, 2048 beyond): consecutive steps of one batch run on a cost-ordered
     # schedule (lipmpc_set_schedule: costliest first, like with like, by the previous launch's iteration counts)
-    scheduled = B > 4096 and os.environ.get("LIPMPC_BENCH_NO_SCHEDULE") != "1"
+    resident = 4096 if N <= 8 else 2048          # one wave per SIMD: 1024 waves of four (N <= 8) or two problems
+    scheduled = B > resident and os.environ.get("LIPMPC_BENCH_NO_SCHEDULE") != "1"
     if scheduled:
         solver.set_schedule(B)
     walker = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5, flags=lipmpc.FLAG_INTERIOR), local_rank)
