@@ -298,14 +298,14 @@ def other_configs(lipmpc, synth, dev):
     o = solver.alloc_outputs(B)
     # scan + constraint assembly in one launch (hulls stay in LDS; (c, eta) rows are what reaches HBM), then the solve
     sen = sensor.alloc_outputs(B, rings=False, c_eta=True)
-    ms_scan = _time_ms(lambda: sensor.sense(state, noise, out=sen))
+    ms_scan = _time_ms(lambda: sensor.sense(state, noise, out=sen, schedule=None))        # robots in index order
     ms_step = _time_ms(lambda: solver.plan_step_batch_c_eta(state, goal, foot, sen["c_eta"], None, out=o))
     # the same scan on a schedule (heaviest robots first, by the previous launch's reading counts: what a closed loop does)
     sched = sensor.make_schedule(B)
     ms_scan_sched = _time_ms(lambda: sensor.sense(state, noise, out=sen, schedule=sched))
     # the two-launch form of round 1 for comparison: rings through HBM, geometry front end in the step kernel
     sen_r = sensor.alloc_outputs(B)
-    ms_scan_r = _time_ms(lambda: sensor.sense(state, noise, out=sen_r))
+    ms_scan_r = _time_ms(lambda: sensor.sense(state, noise, out=sen_r, schedule=None))
     ms_step_r = _time_ms(lambda: solver.plan_step_batch(state, goal, foot, sen_r["obs_xy"], sen_r["obs_nv"], None, out=o))
     out["config5_lidar"] = {"batch": B, "ms_scan": ms_scan, "ms_step": ms_step,
                             "robot_steps_per_s": B / (ms_scan + ms_step) * 1e3,

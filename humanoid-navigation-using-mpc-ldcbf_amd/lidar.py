@@ -67,11 +67,14 @@ class LidarSensor:
         return torch.zeros((int(self.lib.lipmpc_lidar_schedule_words(B)),), dtype=torch.int32, device=self.device)
 
     def sense(self, state, noise=None, with_debug=False, out=None, env_xy=None, env_nv=None, c_eta=False, rings=True,
-              schedule=None):
+              schedule="auto"):
         """state [B,5] device tensor; noise [B,resolution,2] or None -> dict(n_inferred, overflow[, obs_xy, obs_nv][, c_eta]
         [, hits, labels]).  ``c_eta=True``: the constraint assembly runs in the same launch (lipmpc_lidar_c_eta_batch) and
         the dict carries c_eta [B,n_obs_max,4] = (c, eta) of every inferred hull at the robot's CoM -- what
         ``BatchedLipMpc.plan_step_batch_c_eta`` solves against; with ``rings=False`` the hulls never leave the kernel.
+        ``schedule``: a buffer of ``make_schedule(B)``, None (robots in index order), or "auto" (default): with
+        ``c_eta=True`` the sensor keeps one schedule per batch size, so repeated scans of a batch start their robots
+        heaviest first by the previous scan's reading counts (a scheduling hint only: results never depend on it).
         Vertex slots beyond obs_nv keep whatever an earlier call left there when ``out`` is reused.
         ``env_xy`` [B,n_env,v_env,2] / ``env_nv`` [B,n_env] (device tensors): one true map PER ROBOT instead of the
         sensor's shared map (env_shared = 0 of the C ABI)."""
@@ -102,6 +105,15 @@ class LidarSensor:
             n_env, v_env, shared, exy, env = int(env_xy.shape[1]), int(env_xy.shape[2]), 0, env_xy, env_nv
         head = (self.device_index, B, self.resolution, n_env, v_env, shared, self.lidar_range, DBSCAN_EPS,
                 DBSCAN_MIN_SAMPLES, self.n_obs_max, self.v_max, _ptr(state), _ptr(exy), _ptr(env), _ptr(self.table), _ptr(noise))
+        if isinstance(schedule, str):
+            if schedule != "auto":
+                raise ValueError('schedule: a make_schedule(B) buffer, None or "auto"')
+            schedule = None
+            if want_ce and B > 2048:                         # beyond one round of waves (two per SIMD) the start order matters
+                cache = self.__dict__.setdefault("_auto_sched", {})
+                if B not in cache:
+                    cache[B] = self.make_schedule(B)
+                schedule = cache[B]
         if schedule is not None and (not want_ce or schedule.dtype != torch.int32 or schedule.device != dev or not schedule.is_contiguous()
                                      or schedule.numel() != int(self.lib.lipmpc_lidar_schedule_words(B))):
             raise ValueError("schedule: a buffer of make_schedule(B) for this B, with c_eta=True")

@@ -24,21 +24,21 @@ def t(fn, reps=10):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / reps * 1e3
 sen = sensor.alloc_outputs(B, rings=False, c_eta=True)
-print("as it comes          %.1f us" % t(lambda: sensor.sense(state, noise, out=sen)))
+print("as it comes          %.1f us" % t(lambda: sensor.sense(state, noise, out=sen, schedule=None)))
 for name, idx in (("heaviest first", torch.argsort(npts, descending=True)), ("lightest first", torch.argsort(npts))):
     s2, n2 = state[idx].contiguous(), noise[idx].contiguous()
-    print("%-20s %.1f us" % (name, t(lambda: sensor.sense(s2, n2, out=sen))))
+    print("%-20s %.1f us" % (name, t(lambda: sensor.sense(s2, n2, out=sen, schedule=None))))
 sched = sensor.make_schedule(B)
 print("schedule buffer      %.1f us" % t(lambda: sensor.sense(state, noise, out=sen, schedule=sched)), sched[:16].cpu().tolist())
 light = torch.nonzero(npts < 144).flatten()[: (B // 2)]
 if len(light) >= 256:
     s3, n3 = state[light].contiguous(), noise[light].contiguous(); sen3 = sensor.alloc_outputs(len(light), rings=False, c_eta=True)
-    print("only %d robots with < 144 readings  %.1f us" % (len(light), t(lambda: sensor.sense(s3, n3, out=sen3))))
+    print("only %d robots with < 144 readings  %.1f us" % (len(light), t(lambda: sensor.sense(s3, n3, out=sen3, schedule=None))))
 bins = torch.tensor([256, 192, 144, 112, 80], device=dev)
 binid = (npts[:, None] < bins[None, :]).sum(1)                      # 0 = heaviest bin
 idx = torch.argsort(binid, stable=True)
 s4, n4 = state[idx].contiguous(), noise[idx].contiguous()
-print("sorted by BIN only (plain launch)   %.1f us" % t(lambda: sensor.sense(s4, n4, out=sen)))
+print("sorted by BIN only (plain launch)   %.1f us" % t(lambda: sensor.sense(s4, n4, out=sen, schedule=None)))
 idx = torch.argsort(npts, descending=True); s2, n2 = state[idx].contiguous(), noise[idx].contiguous()
 def pers_identity():
     sched.zero_(); sensor.sense(s2, n2, out=sen, schedule=sched)
