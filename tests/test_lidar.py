@@ -36,6 +36,53 @@ def test_oracle_matches_reference_range_finder(golden_dir):
             assert _same_ring(ring, d["inf_xy"][i][j][: d["inf_nv"][i][j]])
 
 
+def _res_case(d, i):
+    R = int(d["res"][i])
+    rings = [d["env"][i][j][: d["env_nv"][i][j]] for j in range(d["env"].shape[1]) if d["env_nv"][i][j] > 0]
+    return d["pos"][i], rings, float(d["lidar_range"][i]), R
+
+
+def test_oracle_matches_reference_range_finder_at_other_resolutions(golden_dir):
+    """lidar_golden_res.npz: the reference's range_finder at 90 / 180 / 270 rays and 1 / 2 m (made by importing it,
+    tests/golden/make_lidar_golden_res.py): hit points bit-exact, scikit-learn's labels, Qhull's rings."""
+    d = np.load(os.path.join(golden_dir, "lidar_golden_res.npz"))
+    for i in range(len(d["pos"])):
+        pos, rings, rng, R = _res_case(d, i)
+        tab = L.ray_table(R)
+        hits, valid = L.lidar_hits(pos, rings, rng, tab)
+        assert np.array_equal(valid, d["valid"][i][:R])
+        assert np.array_equal(hits[valid], d["clean"][i][:R][valid])
+        _, _, labels, inferred = L.range_finder(pos, rings, rng, noise=d["noise"][i][:R], table=tab)
+        assert np.array_equal(labels, d["labels"][i][:R][valid])
+        assert len(inferred) == int((d["inf_nv"][i] > 0).sum())
+        for j, ring in enumerate(inferred):
+            assert _same_ring(ring, d["inf_xy"][i][j][: d["inf_nv"][i][j]])
+
+
+@pytest.mark.gpu
+def test_gpu_lidar_matches_reference_at_other_resolutions(golden_dir):
+    """The kernel against the same reference-made vectors: 90 / 180 / 270 rays, ranges of 1 and 2 m."""
+    torch = pytest.importorskip("torch")
+    import lipmpc
+    d = np.load(os.path.join(golden_dir, "lidar_golden_res.npz"))
+    for i in range(len(d["pos"])):
+        pos, rings, rng, R = _res_case(d, i)
+        sensor = lipmpc.LidarSensor(rings, lidar_range=rng, resolution=R, n_obs_max=12, v_max=40)
+        st = torch.tensor([[pos[0], 0.0, pos[1], 0.0, 0.0]], dtype=torch.float64, device="cuda")
+        noise = torch.as_tensor(np.ascontiguousarray(d["noise"][i][None, :R]), device="cuda")
+        out = sensor.sense(st, noise, with_debug=True)
+        torch.cuda.synchronize()
+        hits = out["hits"][0].cpu().numpy()
+        valid = ~np.isnan(hits[:, 0])
+        assert np.array_equal(valid, d["valid"][i][:R])
+        assert np.array_equal(hits[valid], (d["clean"][i] + d["noise"][i])[:R][valid])
+        assert np.array_equal(out["labels"][0].cpu().numpy(), d["labels"][i][:R])
+        n = int(out["n_inferred"][0]); nv = out["obs_nv"][0].cpu().numpy(); xy = out["obs_xy"][0].cpu().numpy()
+        assert int(out["overflow"][0]) == 0 and n == int((d["inf_nv"][i] > 0).sum())
+        for j in range(n):
+            assert _same_ring(xy[j, : nv[j]], d["inf_xy"][i][j][: d["inf_nv"][i][j]]), (i, j)
+
+
 def test_dbscan_border_and_noise_rules():
     # two 3-point cores 0.5 apart with one border point within eps of both: it joins the first-discovered cluster
     pts = np.array([[0.0, 0.0], [0.1, 0.0], [0.2, 0.0], [0.45, 0.0], [0.7, 0.0], [0.8, 0.0], [0.9, 0.0], [3.0, 3.0]])
