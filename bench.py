@@ -46,6 +46,49 @@ def f_iter(n, m):
     return m * n * (n + 1) + n ** 3 / 3.0 + 12 * m * n + 4 * n * n + 12 * m
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def plan_launch(gpus, env):
+    """What `bench.py --gpus N` has to do before anything touches the GPU (one process per GPU):
+      ("run", None)    this process IS a rank (WORLD_SIZE == --gpus: the driver's torch.distributed.run form), or N = 1;
+      ("spawn", cmd)   N > 1 and no WORLD_SIZE: this process is only the launcher -- it starts N fresh rank processes
+                       (torch.distributed.run, rendezvous on 127.0.0.1) and relays rank 0's JSON line;
+      ("error", msg)   WORLD_SIZE is set and disagrees with --gpus."""
+    ws = env.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != gpus:
+            return "error", f"bench.py: --gpus {gpus} but WORLD_SIZE={ws}: launch one rank per GPU (or drop WORLD_SIZE and let --gpus {gpus} start them)"
+        return "run", None
+    if gpus <= 1:
+        return "run", None
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)]
+    return "spawn", cmd
+
+
+def launch_ranks(cmd, argv):
+    """Parent of a `python bench.py --gpus N` run: a child process per rank (never an exec: nothing here has touched the
+    GPU, and nothing will), rank 0's single JSON line relayed on stdout, the children's exit status as ours."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd + list(argv), env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    for ln in r.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    return r.returncode if r.returncode != 0 else (0 if len(lines) == 1 else 3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -61,6 +104,19 @@ def main():
     ap.add_argument("--all-configs", action="store_true",
                     help="also time BASELINE configs 4 (N=16, 50 obstacles) and 5 (LiDAR front end) as extras")
     args = ap.parse_args()
+
+    what, arg = plan_launch(args.gpus, os.environ)
+    if what == "error":
+        print(arg, file=sys.stderr)
+        sys.exit(2)
+    if what == "spawn":
+        sys.exit(launch_ranks(arg, sys.argv[1:]))
+    if os.environ.get("LIPMPC_BENCH_LAUNCH_ECHO") == "1":
+        # launcher self-test (tests/test_sharding_gloo.py, CPU): a rank only reports how it was started
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+                              "master_addr": os.environ.get("MASTER_ADDR"), "steps": args.steps}), flush=True)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

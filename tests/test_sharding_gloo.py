@@ -88,18 +88,64 @@ def test_two_rank_gloo_sharded_batch():
         assert r[8].shape == (2, 3)
 
 
+def _bench_mod():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_tests", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_bench_launch_plan():
+    """`bench.py --gpus N`: N = 1 or a rank started by the driver runs in place; N > 1 without WORLD_SIZE makes this process
+    the launcher of N ranks; WORLD_SIZE that disagrees with --gpus is an error (never silently a one-GPU run)."""
+    b = _bench_mod()
+    assert b.plan_launch(1, {}) == ("run", None)
+    assert b.plan_launch(1, {"WORLD_SIZE": "1"}) == ("run", None)
+    assert b.plan_launch(8, {"WORLD_SIZE": "8", "RANK": "3"}) == ("run", None)
+    what, cmd = b.plan_launch(4, {})
+    assert what == "spawn" and cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-1].endswith("bench.py")
+    assert b.plan_launch(8, {"WORLD_SIZE": "1"})[0] == "error"
+    assert b.plan_launch(1, {"WORLD_SIZE": "2"})[0] == "error"
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_flag_starts_the_ranks():
+    """plain `python bench.py --gpus 2` (no torchrun around it): two rank processes come up with RANK / WORLD_SIZE /
+    MASTER_ADDR set, rank 0's single JSON line is relayed, exit status 0.  The ranks only echo how they were started
+    (LIPMPC_BENCH_LAUNCH_ECHO=1: no GPU here); the GPU twin of this test runs the solver."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["LIPMPC_BENCH_LAUNCH_ECHO"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3"], env=env,
+                       capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d == {"n_gpus": 2, "local_rank": 0, "master_addr": "127.0.0.1", "steps": 3}
+    # WORLD_SIZE that contradicts --gpus: refused
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=dict(env, WORLD_SIZE="1"),
+                       capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr and r.stdout.strip() == ""
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
 def test_two_rank_bench_with_the_hip_solver():
-    """bench.py's N > 1 path with the HIP solver on both ranks: two processes launched the way the driver launches them
-    (torch.distributed.run), each solving its contiguous shard of ONE batch on the device; on a one-GPU box both ranks
-    share device 0 and gloo stands in for RCCL (LIPMPC_BENCH_REHEARSE=1).  Checks the whole-job bookkeeping of the JSON
-    line: shard sizes, strong scaling, counters gathered over both ranks, value = problems x steps / max time."""
+    """bench.py's N > 1 path with the HIP solver on both ranks, started the plain way: `python bench.py --gpus 2` launches
+    its two rank processes itself (torch.distributed.run underneath, as the driver does), each solving its contiguous shard of
+    ONE batch on the device; on a one-GPU box both ranks share device 0 and gloo stands in for RCCL
+    (LIPMPC_BENCH_REHEARSE=1).  Checks the whole-job bookkeeping of the JSON line: shard sizes, strong scaling, counters
+    gathered over both ranks, value = problems x steps / max time."""
     import json
     import subprocess
-    env = dict(os.environ, LIPMPC_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(LIPMPC_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
            "--total-batch", "3000", "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
