@@ -89,6 +89,94 @@ def launch_ranks(cmd, argv):
     return r.returncode if r.returncode != 0 else (0 if len(lines) == 1 else 3)
 
 
+def make_inputs(lipmpc, synth, B, N, n_obs, lo, rank, dev, local_rank, n_fields=None, walk_steps=30):
+    """The benchmark batch: generate_obstacles-distributed fields (seed = first global index of the shard),
+    delta = 0 and 0.3 variants (0.3 only where the start keeps that clearance), states = live robots of an on-device
+    closed-loop warm-up of 0..walk_steps MPC steps.  n_fields < B: fields reused by several robots (different states)."""
+    hi = 9.5 if N <= 8 else 15.5
+    goal_xy = (10.0, 10.0) if N <= 8 else (16.0, 16.0)
+    nf = n_fields or B
+    xy, nv = synth.synthetic_fields(nf, n_obs, 0.5, hi, (0.0, 0.0), goal_xy, seed=1234 + lo)
+    if nf < B:
+        rep = -(-B // nf)
+        xy, nv = np.tile(xy, (rep, 1, 1, 1))[:B], np.tile(nv, (rep, 1))[:B]
+    walker = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5, flags=lipmpc.FLAG_INTERIOR), local_rank)
+    obs_xy = torch.as_tensor(xy, device=dev)
+    obs_nv = torch.as_tensor(nv, device=dev)
+    goal = torch.tensor([goal_xy], dtype=torch.float64, device=dev).repeat(B, 1).contiguous()
+    st0 = torch.zeros((B, 5), dtype=torch.float64, device=dev)
+    ft0 = torch.ones((B,), dtype=torch.int8, device=dev)
+    ce = walker.plan_step_batch(st0, goal, ft0, obs_xy, obs_nv, None, with_c_eta=True)["c_eta"]
+    clear = torch.where(obs_nv > 0, torch.linalg.norm(ce[:, :, :2], dim=2), torch.full_like(ce[:, :, 0], 1e9)).min(dim=1).values
+    delta = torch.zeros((B,), dtype=torch.float64, device=dev)
+    delta[B // 2:] = torch.where(clear[B // 2:] > 0.45, 0.3, 0.0)
+    state, foot = synth.walk_states(walker, obs_xy, obs_nv, goal, walk_steps, seed=99 + rank, delta=delta)
+    return dict(state=state, foot=foot, goal=goal, obs_xy=obs_xy, obs_nv=obs_nv, delta=delta, walker=walker)
+
+
+def one_step_later(walker, state, foot, goal, obs_xy, obs_nv, delta):
+    """The same robots one MPC step on (interior iterate, as a closed loop advances); a robot whose step fails stays."""
+    o = walker.plan_step_batch(state, goal, foot, obs_xy, obs_nv, delta)
+    st, ft = state.clone(), foot.clone()
+    walker.advance(st, ft, o)
+    return st.contiguous(), ft.contiguous()
+
+
+def _events_ms(fn, reps, dev):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    e0.record()
+    for k in range(reps):
+        fn(k)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) / reps
+
+
+def launch_order_figures(solver, steps, B, sa, sb, goal, obs_xy, obs_nv, delta, out, dev):
+    """What the launch order is worth on this shard, outside the timed region (solves/s of this rank): index order, and the
+    replayed batch (the order a launch left applied to the very same problems: an exact prediction of every cost -- the
+    upper bound no closed loop gets; the timed `value` uses the one-step-stale order)."""
+    both = lambda k: solver.plan_step_batch((sb if k & 1 else sa)[0], goal, (sb if k & 1 else sa)[1], obs_xy, obs_nv, delta, out=out)
+    same = lambda k: solver.plan_step_batch(sa[0], goal, sa[1], obs_xy, obs_nv, delta, out=out)
+    same(0); same(1)
+    ms_replay = _events_ms(same, steps, dev)
+    solver.set_schedule(0)
+    both(0)
+    ms_index = _events_ms(both, steps, dev)
+    solver.set_schedule(B)
+    both(0); both(1)
+    return {"index_order": B / ms_index * 1e3, "replayed_batch_exact_prediction_upper_bound": B / ms_replay * 1e3}
+
+
+def roofline_frac(achieved, peak):
+    """`frac` is a fraction only while the dense algorithmic count stays below what the hardware can execute; the structured
+    kernel executes a fraction of the dense count, so at N = 16 / 50 obstacles the ratio exceeds 1: it is then reported under
+    its real name and `frac` is null (the utilisation figure is executed_frac_of_peak)."""
+    r = achieved / peak
+    return {"frac": r} if r <= 1.0 else {"frac": None, "dense_equiv_ratio": r}
+
+
+def transfer_times(inp, out, dev, kern_ms):
+    """Host<->device copies of ONE step's inputs and outputs through pinned host buffers (reported separately,
+    never part of `value`: the timed region starts with the inputs resident in HBM)."""
+    ins = [inp[k] for k in ("state", "goal", "foot", "delta", "obs_xy", "obs_nv")]
+    outs = [out[k] for k in ("U", "X", "theta", "omega", "obj", "status", "iters", "active")]
+    h_in = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t) for t in ins]
+    h_out = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in outs]
+    d_in = [torch.empty_like(t) for t in ins]
+    h2d = _events_ms(lambda k: [d.copy_(h, non_blocking=True) for d, h in zip(d_in, h_in)], 10, dev)
+    d2h = _events_ms(lambda k: [h.copy_(d, non_blocking=True) for h, d in zip(h_out, outs)], 10, dev)
+    nb = lambda ts: int(sum(t.numel() * t.element_size() for t in ts))
+    B = ins[0].shape[0]
+    return {"h2d_ms": h2d, "d2h_ms": d2h, "h2d_bytes": nb(ins), "d2h_bytes": nb(outs),
+            "h2d_GBps": nb(ins) / h2d / 1e6, "d2h_GBps": nb(outs) / d2h / 1e6,
+            "solves_per_s_with_copies_serialised": B / (h2d + kern_ms + d2h) * 1e3,
+            "note": "one step's inputs (state, goal, first_foot, delta, obstacle rings) and outputs (U, X, theta, omega, obj, status, "
+                    "iters, active) through pinned host memory, copies and kernel back to back on one stream (no overlap): "
+                    "what a caller that keeps nothing resident would see; not `value`"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,8 +189,10 @@ def main():
     ap.add_argument("--obstacles", type=int, default=10)
     ap.add_argument("--finish-rounds", type=int, default=0, help="lipmpc_params.finish_rounds (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the compact extras (BASELINE configs 3 on one GPU, 4 and 5: a few seconds; never `value`)")
     ap.add_argument("--all-configs", action="store_true",
-                    help="also time BASELINE configs 4 (N=16, 50 obstacles) and 5 (LiDAR front end) as extras")
+                    help="extras in full: + config 5 through HBM rings and in closed loop (fleet of 4096 robots, 30 samples)")
     args = ap.parse_args()
 
     what, arg = plan_launch(args.gpus, os.environ)
@@ -171,28 +261,28 @@ def main():
     walker = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5, flags=lipmpc.FLAG_INTERIOR), local_rank)
 
     # ---- synthetic inputs (seeded per rank), placed in HBM before the timed region -------------
-    # seeded per shard: rank r of a sharded job generates exactly its slice's fields (seed = first global index)
-    xy, nv = synth.synthetic_fields(B, n_obs, 0.5, hi, (0.0, 0.0), goal_xy, seed=1234 + lo)
-    obs_xy = torch.as_tensor(xy, device=dev)
-    obs_nv = torch.as_tensor(nv, device=dev)
-    goal = torch.tensor([goal_xy], dtype=torch.float64, device=dev).repeat(B, 1).contiguous()
-    # delta = 0 and 0.3 variants; 0.3 only where the start keeps that clearance
-    st0 = torch.zeros((B, 5), dtype=torch.float64, device=dev)
-    ft0 = torch.ones((B,), dtype=torch.int8, device=dev)
-    ce = walker.plan_step_batch(st0, goal, ft0, obs_xy, obs_nv, None, with_c_eta=True)["c_eta"]
-    clear = torch.where(obs_nv > 0, torch.linalg.norm(ce[:, :, :2], dim=2), torch.full_like(ce[:, :, 0], 1e9)).min(dim=1).values
-    delta = torch.zeros((B,), dtype=torch.float64, device=dev)
-    delta[B // 2:] = torch.where(clear[B // 2:] > 0.45, 0.3, 0.0)
-    state, foot = synth.walk_states(walker, obs_xy, obs_nv, goal, 30, seed=99 + rank, delta=delta)
+    inp = make_inputs(lipmpc, synth, B, N, n_obs, lo, rank, dev, local_rank)
+    state, foot, goal, obs_xy, obs_nv, delta, walker = (inp[k] for k in ("state", "foot", "goal", "obs_xy", "obs_nv", "delta", "walker"))
     out = solver.alloc_outputs(B)
+    # On a schedule the order a launch runs in is the one the PREVIOUS launch left.  Replaying one batch would make that an
+    # exact prediction of every problem's cost, which no closed loop gets; so the timed launches alternate between the
+    # batch and the same robots ONE MPC STEP LATER: each launch is placed by the costs of the neighbouring step, as the
+    # samples of a closed loop are, and the workload stays stationary.
+    state_b, foot_b = one_step_later(walker, state, foot, goal, obs_xy, obs_nv, delta) if scheduled else (state, foot)
     torch.cuda.synchronize(dev)
 
     def barrier():
         if use_dist:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        solver.plan_step_batch(state, goal, foot, obs_xy, obs_nv, delta, out=out)
+    def step(k):
+        if scheduled and (k & 1):
+            solver.plan_step_batch(state_b, goal, foot_b, obs_xy, obs_nv, delta, out=out)
+        else:
+            solver.plan_step_batch(state, goal, foot, obs_xy, obs_nv, delta, out=out)
+
+    for k in range(args.warmup + (args.warmup & 1 if scheduled else 0)):      # (an even count: the timed loop starts on the batch)
+        step(k)
     torch.cuda.synchronize(dev)
     barrier()
     torch.cuda.synchronize(dev)
@@ -201,7 +291,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
-        solver.plan_step_batch(state, goal, foot, obs_xy, obs_nv, delta, out=out)
+        step(k)
         ev[k][1].record()
     torch.cuda.synchronize(dev)
     barrier()
@@ -209,6 +299,14 @@ def main():
     elapsed = time.perf_counter() - t0
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    order_detail = None
+    if scheduled:
+        order_detail = launch_order_figures(solver, args.steps, B, (state, foot), (state_b, foot_b), goal, obs_xy, obs_nv, delta, out, dev)
+        order_detail["one_step_stale_order"] = B * args.steps / elapsed
+    # the answers of the batch itself, with the certificate margins the CPU check filters on (outside the timed region:
+    # the identification margin costs logarithms)
+    out = solver.plan_step_batch(state, goal, foot, obs_xy, obs_nv, delta, with_diag=True)
+    torch.cuda.synchronize(dev)
     status = out["status"].cpu().numpy()
     iters = out["iters"].cpu().numpy()
     n_ok = int(np.sum((status == 0) | (status == 4)))
@@ -254,18 +352,25 @@ def main():
                                    "(generate_obstacles distribution), states from closed-loop warm-up, delta in {0,0.3}",
                        "total_batch": total, "batch_rank0": B, "horizon": N, "obstacles": n_obs,
                        "parallelism": f"contiguous batch shards x{world}, no data-path collective",
-                       "launch_order": "cost-ordered schedule from the previous step (lipmpc_set_schedule)" if scheduled else "index order"},
+                       "launch_order": ("cost-ordered schedule (lipmpc_set_schedule), each launch placed by the costs of the same robots one "
+                                        "MPC step away (the timed launches alternate between two consecutive steps of the batch)") if scheduled else "index order",
+                       "launch_order_solves_per_s_rank0": order_detail},
             "solver": {"mean_iters": float(iters.mean()), "max_iters": int(iters.max()),
                        "status_hist": {str(k): int(v) for k, v in zip(*np.unique(status, return_counts=True))},
                        "solved_frac": n_ok / B},
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
+                         **roofline_frac(achieved, peak), "traffic": traffic,
                          "kernel": "plan_step_kernel", "kernel_ms": kern_ms,
                          "flops_per_launch_algorithmic": flops_launch,
                          "executed_fp64_flops_per_launch": executed,
                          "executed_tflops": (executed / (kern_ms * 1e-3) / 1e12) if executed else None,
                          "executed_frac_of_peak": (executed / (kern_ms * 1e-3) / 1e12 / peak) if executed else None,
                          "peak_source": peak_src, "peak_datasheet": FP64_PEAK_DATASHEET,
+                         "frac_of_datasheet_peak_on_wall_ms_per_step": flops_launch / (t_max / args.steps) / 1e12 / FP64_PEAK_DATASHEET,
+                         "sources": {"achieved": "this run: iterations of this run's answers x F_iter / kernel_ms (HIP events of this run)",
+                                     "peak": peak_src,
+                                     "traffic": "profiles/traffic.json (builder's rocprofv3 --pmc run of this workload, tools/profile_round.sh)",
+                                     "executed_fp64_flops_per_launch": "profiles/traffic.json (same PMC run: SQ_INSTS_VALU_*_F64 x 64 lanes)"},
                          "peak_one_wave_per_simd": (peak_rec or {}).get("fp64_fma_tflops", {}).get("1_wave_per_simd"),
                          "note": "compute-bound FP64 on the vector ALU (no MFMA is issued: SQ_INSTS_VALU_MFMA_MOPS_F64 = 0); "
                                  "achieved = SURVEY 8d DENSE algorithmic count F_iter(n,m) x the iterations each problem took "
@@ -279,8 +384,10 @@ def main():
             warm_walker = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5,
                                                                    flags=lipmpc.FLAG_INTERIOR | lipmpc.FLAG_WARM_START), local_rank)
             res["rollout_warm_start"] = rollout_throughput(lipmpc, warm_walker, obs_xy, obs_nv, goal, delta, dev)
-        if world == 1 and args.all_configs:
-            res["other_configs"] = other_configs(lipmpc, synth, dev)
+        if world == 1:
+            res["transfers"] = transfer_times(inp, out, dev, kern_ms)
+        if world == 1 and not args.no_other_configs:
+            res["other_configs"] = other_configs(lipmpc, synth, dev, full=args.all_configs)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(P, state, goal, foot, obs_xy, obs_nv, delta, out)
         if real_stdout is not None:
@@ -322,24 +429,66 @@ def _time_ms(fn, reps=10):
     return e0.elapsed_time(e1) / reps
 
 
-def other_configs(lipmpc, synth, dev):
-    """Extras (never `value`): BASELINE config 4 and config 5 on one GPU, smaller synthetic batches so the run stays short."""
-    out = {}
-    # config 4: N=16, 50 obstacles (streamed LDCBF rows, 32 lanes per problem)
-    B, N, n_obs = 1024, 16, 50
-    xy, nv = synth.synthetic_fields(B, n_obs, 0.5, 15.5, (0.0, 0.0), (16.0, 16.0), seed=77)
-    oxy, onv = torch.as_tensor(xy, device=dev), torch.as_tensor(nv, device=dev)
-    goal = torch.tensor([[16.0, 16.0]], dtype=torch.float64, device=dev).repeat(B, 1).contiguous()
-    walker = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5, flags=lipmpc.FLAG_INTERIOR), dev.index)
-    solver = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5), dev.index)
-    state, foot = synth.walk_states(walker, oxy, onv, goal, 20, seed=5)
+def _scheduled_ms(solver, walker, inp, B, dev, reps=6):
+    """ms per launch of one batch on the cost-ordered schedule, each launch placed by the costs of the same robots one MPC
+    step away (see main()); and in index order."""
+    sa = (inp["state"], inp["foot"])
+    sb = one_step_later(walker, inp["state"], inp["foot"], inp["goal"], inp["obs_xy"], inp["obs_nv"], inp["delta"])
     o = solver.alloc_outputs(B)
-    ms = _time_ms(lambda: solver.plan_step_batch(state, goal, foot, oxy, onv, None, out=o))
-    st = o["status"].cpu().numpy()
-    out["config4_N16_50obs"] = {"batch": B, "ms_per_step": ms, "solves_per_s": B / ms * 1e3,
-                                "mean_iters": float(o["iters"].double().mean()),
-                                "status_hist": {str(k): int(v) for k, v in zip(*np.unique(st, return_counts=True))}}
-    # config 5: LiDAR scan -> clusters -> hulls -> step, 4096 robots on one CROWDED-style map (20 obstacles)
+    both = lambda k: solver.plan_step_batch((sb if k & 1 else sa)[0], inp["goal"], (sb if k & 1 else sa)[1], inp["obs_xy"], inp["obs_nv"],
+                                            inp["delta"], out=o)
+    both(0)
+    ms_index = _events_ms(both, reps, dev)
+    solver.set_schedule(B)
+    both(0); both(1)
+    ms_sched = _events_ms(both, reps, dev)
+    solver.set_schedule(0)
+    solver.plan_step_batch(sa[0], inp["goal"], sa[1], inp["obs_xy"], inp["obs_nv"], inp["delta"], out=o)
+    torch.cuda.synchronize(dev)
+    return ms_sched, ms_index, o
+
+
+def other_configs(lipmpc, synth, dev, full=False):
+    """Extras of the default run (never `value`): BASELINE configs[2] (32768 robots) on ONE GPU, configs[3] (N = 16, 50
+    obstacles, B = 4096) and configs[4] (LiDAR front end, B = 4096), each a handful of launches.  Fields are reused by
+    several robots (different states) so that the host-side generator stays short.  full: + the round-1 form of config 5
+    (rings through HBM) and the closed-loop fleet."""
+    out = {}
+    # config 3 on one GPU: 32768 robots at N = 8 / 10 obstacles, on the schedule (8 rounds of waves)
+    B, N, n_obs = 32768, 8, 10
+    inp = make_inputs(lipmpc, synth, B, N, n_obs, 50000, 7, dev, dev.index, n_fields=2048)
+    solver = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5), dev.index)
+    ms_s, ms_i, o = _scheduled_ms(solver, inp["walker"], inp, B, dev)
+    st, it = o["status"].cpu().numpy(), o["iters"].cpu().numpy()
+    flops = f_iter(2 * N, 9 * N + N * n_obs) * float(it.sum())
+    peak = fp64_peak()[0]
+    out["config3_32768_on_one_gpu"] = {"batch": B, "ms_per_step": ms_s, "solves_per_s": B / ms_s * 1e3, "solves_per_s_index_order": B / ms_i * 1e3,
+                                       "mean_iters": float(it.mean()), "status_hist": {str(k): int(v) for k, v in zip(*np.unique(st, return_counts=True))},
+                                       **{("roofline_" + k): v for k, v in roofline_frac(flops / (ms_s * 1e-3) / 1e12, peak).items()}}
+    del inp, solver, o
+    # config 4: N = 16, 50 obstacles (streamed LDCBF rows, 32 lanes per problem), B = 4096 = two rounds of waves
+    B, N, n_obs = 4096, 16, 50
+    inp = make_inputs(lipmpc, synth, B, N, n_obs, 70000, 5, dev, dev.index, n_fields=512, walk_steps=20)
+    solver = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5), dev.index)
+    ms_s, ms_i, o = _scheduled_ms(solver, inp["walker"], inp, B, dev)
+    st, it = o["status"].cpu().numpy(), o["iters"].cpu().numpy()
+    flops = f_iter(2 * N, 9 * N + N * n_obs) * float(it.sum())
+    traffic = executed = None
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(f"N{N}_obs{n_obs}_B{B}") or {}
+        traffic, executed = rec.get("hbm_bytes"), rec.get("executed_fp64_flops")
+    except Exception:
+        pass
+    out["config4_N16_50obs"] = {"batch": B, "ms_per_step": ms_s, "solves_per_s": B / ms_s * 1e3, "solves_per_s_index_order": B / ms_i * 1e3,
+                                "mean_iters": float(it.mean()), "max_iters": int(it.max()),
+                                "status_hist": {str(k): int(v) for k, v in zip(*np.unique(st, return_counts=True))},
+                                "uncertified_frac": float((st == 4).mean()),
+                                **{("roofline_" + k): v for k, v in roofline_frac(flops / (ms_s * 1e-3) / 1e12, peak).items()},
+                                "executed_fp64_flops_per_launch": executed, "traffic": traffic,
+                                "executed_frac_of_peak": (executed / (ms_i * 1e-3) / 1e12 / peak) if executed else None,
+                                "sources": {"executed_fp64_flops_per_launch, traffic": "profiles/traffic.json (builder's rocprofv3 --pmc run, index order)"}}
+    del inp, solver, o
+    # config 5: LiDAR scan -> clusters -> hulls -> (c, eta) in one launch, then the step, 4096 robots on one CROWDED-style map (20 obstacles)
     B, N = 4096, 3
     exy, env = synth.synthetic_fields(1, 20, -1.0, 6.0, (-5.0, -5.0), (50.0, 50.0), seed=9, delta=0.6)
     rings = [exy[0, j, : env[0, j]] for j in range(20) if env[0, j] > 0]
@@ -348,27 +497,35 @@ def other_configs(lipmpc, synth, dev):
     pos = torch.rand((B, 2), dtype=torch.float64, device=dev, generator=gen) * 7.0 - 1.0
     state = torch.zeros((B, 5), dtype=torch.float64, device=dev); state[:, 0] = pos[:, 0]; state[:, 2] = pos[:, 1]
     noise = 0.01 * torch.randn((B, 360, 2), dtype=torch.float64, device=dev, generator=gen)
+    # the same robots one sample later (each has moved a step of ~5 cm): the scheduled scan of a sample is placed by the
+    # reading counts of the neighbouring sample, as in a closed loop, not by its own
+    state_b = state.clone(); state_b[:, 0] += 0.04; state_b[:, 2] += 0.03
+    noise_b = 0.01 * torch.randn((B, 360, 2), dtype=torch.float64, device=dev, generator=gen)
     goal = torch.tensor([[5.0, 5.0]], dtype=torch.float64, device=dev).repeat(B, 1).contiguous()
     foot = torch.ones((B,), dtype=torch.int8, device=dev)
     solver = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=12, v_max=32), dev.index)
     o = solver.alloc_outputs(B)
-    # scan + constraint assembly in one launch (hulls stay in LDS; (c, eta) rows are what reaches HBM), then the solve
     sen = sensor.alloc_outputs(B, rings=False, c_eta=True)
     ms_scan = _time_ms(lambda: sensor.sense(state, noise, out=sen, schedule=None))        # robots in index order
-    ms_step = _time_ms(lambda: solver.plan_step_batch_c_eta(state, goal, foot, sen["c_eta"], None, out=o))
-    # the same scan on a schedule (heaviest robots first, by the previous launch's reading counts: what a closed loop does)
+    ms_step = _time_ms(lambda: solver.plan_step_batch_c_eta(state, goal, foot, sen["c_eta"], None, out=o, overflow=sen["overflow"]))
     sched = sensor.make_schedule(B)
-    ms_scan_sched = _time_ms(lambda: sensor.sense(state, noise, out=sen, schedule=sched))
+    alt = lambda k: sensor.sense(state_b if k & 1 else state, noise_b if k & 1 else noise, out=sen, schedule=sched)
+    alt(0); alt(1)
+    ms_scan_sched = _events_ms(alt, 10, dev)
+    sensor.sense(state, noise, out=sen, schedule=None)
+    out["config5_lidar"] = {"batch": B, "ms_scan": ms_scan, "ms_step": ms_step,
+                            "robot_steps_per_s": B / (ms_scan + ms_step) * 1e3,
+                            "ms_scan_scheduled": ms_scan_sched, "robot_steps_per_s_scheduled": B / (ms_scan_sched + ms_step) * 1e3,
+                            "schedule": "heaviest first by the reading counts of the neighbouring sample (robots moved one step)",
+                            "mean_inferred_obstacles": float(sen["n_inferred"].double().mean()),
+                            "overflow": int(sen["overflow"].sum())}
+    if not full:
+        return out
     # the two-launch form of round 1 for comparison: rings through HBM, geometry front end in the step kernel
     sen_r = sensor.alloc_outputs(B)
     ms_scan_r = _time_ms(lambda: sensor.sense(state, noise, out=sen_r, schedule=None))
     ms_step_r = _time_ms(lambda: solver.plan_step_batch(state, goal, foot, sen_r["obs_xy"], sen_r["obs_nv"], None, out=o))
-    out["config5_lidar"] = {"batch": B, "ms_scan": ms_scan, "ms_step": ms_step,
-                            "robot_steps_per_s": B / (ms_scan + ms_step) * 1e3,
-                            "ms_scan_scheduled": ms_scan_sched, "robot_steps_per_s_scheduled": B / (ms_scan_sched + ms_step) * 1e3,
-                            "rings_through_hbm": {"ms_scan": ms_scan_r, "ms_step": ms_step_r},
-                            "mean_inferred_obstacles": float(sen["n_inferred"].double().mean()),
-                            "overflow": int(sen["overflow"].sum())}
+    out["config5_lidar"]["rings_through_hbm"] = {"ms_scan": ms_scan_r, "ms_step": ms_step_r}
     # config 5 in closed loop: the same fleet walking 30 samples through the map, one captured HIP graph per sample
     fleet = lipmpc.UnknownEnvFleet(rings, N_horizon=N, lidar_range=1.5, resolution=360, n_obs_max=12, v_max=32, device=dev.index)
     st0 = torch.zeros((B, 5), dtype=torch.float64, device=dev)
@@ -431,8 +588,6 @@ def cpu_baseline(P, state, goal, foot, obs_xy, obs_nv, delta, out):
     U = out["U"].cpu().numpy()
     ok = (r1["status"] == 0) & (out["status"].cpu().numpy() == 0)
     du = float(np.max(np.abs(U[ok] - r1["U"][ok]))) if ok.any() else float("nan")
-    # active sets, bit for bit, on the certified problems whose certificate is decisive (margin >= 1e-6: a weakly
-    # active row may legitimately sit on either side)
     # UNCERTIFIED answers (interior-point iterate handed out as usable) against the optimum the oracle certifies when its
     # finish may run 64 rounds
     unc = np.where(out["status"].cpu().numpy() == 4)[0]
@@ -444,8 +599,13 @@ def cpu_baseline(P, state, goal, foot, obs_xy, obs_nv, delta, out):
         c64 = r64["status"] == 0
         n_unc_cert = int(c64.sum())
         du_unc = float(np.max(np.abs(U[unc][c64] - r64["U"][c64]))) if c64.any() else None
+    # active sets, bit for bit, on the problems whose certificate is decisive on BOTH sides (tests/helpers.py::decisive_mask,
+    # the filter the parity tests use: a weakly active row -- multiplier or slack within 1e-6 of zero -- may legitimately
+    # sit on either side of the set)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import decisive_mask
     act_g = out["active"].cpu().numpy().view(np.uint64)
-    firm = ok & (r1["diag"][:, 3] >= 1e-6)
+    firm = decisive_mask(ok, out["diag"].cpu().numpy(), r1["diag"])
     act_mism = int(np.sum(np.any(act_g[firm] != r1["active"][firm], axis=1)))
     return {"value": done / t_all, "unit": "solves/s", "cores": cores, "kind": "port",
             "sample": f"the same {B}-problem batch x {reps} passes, OpenMP over problems ({cores} threads); "

@@ -32,11 +32,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    # LIPMPC_LIB: another build of the same library (dev tools only: the instrumented / historical variants of tools/*.sh
+    # are loaded from their own path instead of being copied over the shipped file)
+    path = os.environ.get("LIPMPC_LIB") or LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} not found: build the HIP extension first "
+            f"{path} not found: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C <package>/csrc)")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
     lib.lipmpc_default_params.argtypes = [C.POINTER(LipmpcParamsC)]
     lib.lipmpc_default_params.restype = i32
@@ -50,7 +53,7 @@ def load():
     lib.lipmpc_active_words.restype = i64
     lib.lipmpc_plan_step_batch.argtypes = [vp, i64] + [vp] * 18
     lib.lipmpc_plan_step_batch.restype = i32
-    lib.lipmpc_plan_step_batch_c_eta.argtypes = [vp, i64] + [vp] * 16
+    lib.lipmpc_plan_step_batch_c_eta.argtypes = [vp, i64] + [vp] * 17
     lib.lipmpc_plan_step_batch_c_eta.restype = i32
     lib.lipmpc_advance_batch.argtypes = [vp, i64] + [vp] * 6
     lib.lipmpc_advance_batch.restype = i32

@@ -47,8 +47,11 @@ constexpr int IPM_SLOW_FROM = 8;
 constexpr double IPM_SLOW_RATIO = 0.9, IPM_SLOW_SIGMA = 0.5;   // no progress in mu (from iteration 8 on) -> centre up to half way
 constexpr double FIN_RHO = 1e10;
 constexpr double FIN_EPS = 1e-9;
-constexpr int FIN_ROUNDS = 5;            // default of lipmpc_params.finish_rounds for N <= 8 (tail latency: see DESIGN.md)
-constexpr int FIN_ROUNDS_LONG = 10;      // ... and for longer horizons (worse conditioned, more exchanges needed)
+constexpr int FIN_ROUNDS = 8;            // default of lipmpc_params.finish_rounds for N <= 8 (tail latency: see DESIGN.md)
+constexpr int FIN_ROUNDS_LONG = 16;      // ... and for longer horizons (worse conditioned, more exchanges needed)
+constexpr double FIN_RHO_POLISH = 1e12, FIN_POLISH_TOL = 1e-10;    // polish round of the finish (oracle: finish_active_set, 5.)
+constexpr double FIN_GD_MIN = 1e-14;     // ratio test: a direction component below this does not run into its row
+constexpr double FIN_DUAL_REL = 1e-14;   // stationarity tolerance of the certificate: FIN_EPS + this x largest multiplier
 constexpr double FIN_IDENT = 1e5;   // initial working set z > FIN_IDENT * s: a deliberate under-estimate (oracle docstring)
 constexpr int FIN_INNER = 6;
 constexpr double FIN_INNER_TOL = 1e-11;
@@ -352,6 +355,7 @@ struct StepIn {
   double vmax_x, vmax_y, alpha_over_pi, omega_max;   // per-problem bounds (handle values unless overridden)
   long pb;          // problem index (obstacle arrays, step outputs)
   bool valid;       // false: padding group of the last workgroup (computes, never writes)
+  bool sensor_overflow = false;   // the producer of the given half-spaces dropped obstacles (lipmpc_lidar_c_eta_batch: overflow): not solved
 };
 struct StepOut {
   int status, iters;
@@ -872,6 +876,7 @@ __device__ __forceinline__ StepOut step_body(
   bool done = false;
   if (front_flag & 2) { status = LIPMPC_STATUS_DEGENERATE; done = true; }
   else if (front_flag & 1) { status = LIPMPC_STATUS_INFEASIBLE; done = true; }
+  if (in.sensor_overflow) { status = LIPMPC_STATUS_SENSOR_OVERFLOW; done = true; }     // a truncated obstacle list is not planned against
   if (m_rows == 0.0 && !done) { status = LIPMPC_STATUS_SOLVED; done = true; q = var_on ? gc : 0.0; }
 
   // row-presence masks as 0/1 doubles: an absent row keeps s = 1, z = 0 and is neutralised by four
@@ -1109,11 +1114,19 @@ __device__ __forceinline__ StepOut step_body(
   double diag_rounds = 0.0, diag_eres = 0.0, diag_cert = 0.0;
 
   // ---- certified active-set finish --------------------------------------------------------------
+  // A PRIMAL active-set method from the interior-point iterate (oracle: finish_active_set): per round one factorisation of
+  // K_A = 2I + rho G_A^T G_A, the minimiser x_A on the working set by the method of multipliers, a ratio test along
+  // d = x_A - x over the rows outside A (a blocked step stops at the blocking row, which joins A), otherwise the rows
+  // with a negative multiplier leave A, otherwise x_A is the optimum.  x stays feasible, the objective never increases, and a
+  // blocking row is never dependent on A (g.d = 0 for every row in A's span), which is what the degenerate vertices of
+  // the long-horizon / many-obstacle problems need.
   const bool ipm_ok = (status == LIPMPC_STATUS_SOLVED) && (m_rows > 0.0);
   if (!(P.flags & LIPMPC_FLAG_INTERIOR)) {
     bool fin_done = !ipm_ok;        // groups that never converged skip the finish
     bool certified = false;
-    double qf = q;
+    double rho = FIN_RHO;           // penalty of the equality solves (FIN_RHO_POLISH after a polish request, below)
+    double xf = q;                  // the feasible point the rounds move
+    double qf = q;                  // minimiser on the working set
     double y[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) y[i] = act[i] ? z[i] : 0.0;
@@ -1122,11 +1135,27 @@ __device__ __forceinline__ StepOut step_body(
       for (int t = 0; t < NOBS_S; ++t)
         if (!((abits >> t) & 1u)) lds_sz[grp][t][lane][1] = 0.0;
     }
+    // slack function of streamed row t at the stage position / its ratio-test entry: evaluated twice per round (value,
+    // then index of the minimum), so both evaluations must round alike
+    auto s_slack = [&](int t, double fx, double fy) -> double {
+#pragma clang fp contract(off)
+      double ex, ey, bb;
+      s_obs(t, ex, ey, bb);
+      return ex * fx + ey * fy - bb;
+    };
+    auto s_ratio = [&](int t, double fx, double fy, double ddx, double ddy) -> double {
+#pragma clang fp contract(off)
+      double ex, ey, bb;
+      s_obs(t, ex, ey, bb);
+      const double sl = ex * fx + ey * fy - bb, gd = -(ex * ddx + ey * ddy);       // g = -eta
+      const bool cand = gd > FIN_GD_MIN;
+      return cand ? fmax(sl + gd, 0.0) / (cand ? gd : 1.0) : INFINITY;
+    };
     for (int rnd = 0; rnd < P.fin_rounds; ++rnd) {
       if (__all(fin_done)) break;
       double d[NR];
 #pragma unroll
-      for (int i = 0; i < NR; ++i) d[i] = act[i] ? FIN_RHO : 0.0;
+      for (int i = 0; i < NR; ++i) d[i] = act[i] ? rho : 0.0;
       double cxs = 0.0, cxys = 0.0, cys = 0.0;
       if constexpr (STREAM) {
 #pragma unroll STREAM_UNROLL
@@ -1134,13 +1163,14 @@ __device__ __forceinline__ StepOut step_body(
           if ((abits >> t) & 1u) {
             double ex, ey, bb;
             s_obs(t, ex, ey, bb);
-            cxs = fma(FIN_RHO * ex, ex, cxs); cxys = fma(FIN_RHO * ex, ey, cxys); cys = fma(FIN_RHO * ey, ey, cys);
+            cxs = fma(rho * ex, ex, cxs); cxys = fma(rho * ex, ey, cxys); cys = fma(rho * ey, ey, cys);
           }
         }
       }
       K_rows(d, cxs, cxys, cys);
       const bool fok = factor();
-      double eres = INFINITY;
+      qf = xf;                                         // the equality solve starts at the current point
+      double eres = INFINITY, rd_g = 0.0, r_g = 0.0;
       for (int in = 0; in <= FIN_INNER; ++in) {
         slack_values(qf);
         const double fx = cx_, fy = cy_;               // stage position of qf
@@ -1162,14 +1192,16 @@ __device__ __forceinline__ StepOut step_body(
               const double yt = lds_sz[grp][t][lane][1];
               rmax_l = fmax(rmax_l, fabs(r));
               ayx = fma(ex, yt, ayx); ayy = fma(ey, yt, ayy);
-              awx = fma(ex, FIN_RHO * r, awx); awy = fma(ey, FIN_RHO * r, awy);
+              awx = fma(ex, rho * r, awx); awy = fma(ey, rho * r, awy);
             }
           }
         }
         const double gty = GT_rows(y, ayx, ayy);
         const double rd = var_on ? (2.0 * (qf - gc) + gty) : 0.0;
         const double eprev = eres;
-        eres = fmax(gmax<G>(fabs(rd)), gmax<G>(rmax_l));
+        rd_g = gmax<G>(fabs(rd));
+        r_g = gmax<G>(rmax_l);
+        eres = fmax(rd_g, r_g);
         // converged, out of corrections, or stalled on its rounding floor below what the certificate needs (an
         // ill-conditioned working set sits at 1e-10 forever: four corrections of ~1.7 us each, per round, for nothing)
         const bool stop = (eres <= FIN_INNER_TOL) || (in == FIN_INNER) || (eres <= FIN_EPS && eres > FIN_STALL * eprev);
@@ -1189,94 +1221,105 @@ __device__ __forceinline__ StepOut step_body(
                 double ex, ey, bb;
                 s_obs(t, ex, ey, bb);
                 const double slk_t = ex * fx + ey * fy - bb, dl_t = -(ex * ddx + ey * ddy);
-                lds_sz[grp][t][lane][1] += FIN_RHO * (dl_t - slk_t);
+                lds_sz[grp][t][lane][1] += rho * (dl_t - slk_t);
               }
             }
           }
         }
       }
       // (slk holds the slack functions of the final qf: every pass of the loop above evaluates them before it decides to stop)
-      // most negative multiplier in A, most violated row outside A: the VALUES first (two group minima).  Nine rounds in
-      // ten end here with neither below -eps -- certified -- and never look at a row index; only a group that has to
-      // exchange a row finds which one: the lowest canonical index among the rows attaining the minimum (numpy's argmin
-      // order), one integer group minimum each.
-      double ymin = INFINITY, smin = INFINITY;
-      auto s_slack = [&](int t, double fx, double fy) -> double {     // slack function of streamed row t at the stage position
-#pragma clang fp contract(off)                                        // (evaluated twice below: both must round alike)
-        double ex, ey, bb;
-        s_obs(t, ex, ey, bb);
-        return ex * fx + ey * fy - bb;
-      };
+      // ratio test along d = qf - xf: slack at x = slack at qf + g.d; entry of a row outside A the direction runs into:
+      // max(slack at x, 0) / g.d; the smallest entry below 1 blocks the step
+      const double fx = cx_, fy = cy_;                  // stage position of qf (streamed rows)
+      const double dd = qf - xf;
+      double gd[NR], rr[NR];
+      rows_dir(dd, gd);
+      const double ddx = cx_, ddy = cy_;                // stage direction
+      double rbest = INFINITY;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const bool cand = pres[i] & !act[i] & (gd[i] > FIN_GD_MIN);
+        rr[i] = cand ? fmax(slk[i] + gd[i], 0.0) / (cand ? gd[i] : 1.0) : INFINITY;
+        rbest = fmin(rbest, rr[i]);
+      }
+      // multipliers on A and slack functions outside A at qf: the VALUES first (group extrema).  Most rounds end here,
+      // certified, and never look at a row index; only a group that has to exchange a row finds which one: the lowest
+      // canonical index among the rows attaining the extremum (numpy's argmin order), one integer group minimum each.
+      double ymin = INFINITY, ymax = 0.0, smin = INFINITY;
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
         const bool ta = act[i], ti = pres[i] & !ta;
         ymin = fmin(ymin, ta ? y[i] : INFINITY);
+        ymax = fmax(ymax, ta ? y[i] : 0.0);
         smin = fmin(smin, ti ? slk[i] : INFINITY);
       }
       if constexpr (STREAM) {
-        const double fx = cx_, fy = cy_;
 #pragma unroll STREAM_UNROLL
         for (int t = 0; t < NOBS_S; ++t) {
           if ((pbits >> t) & 1u) {
-            if ((abits >> t) & 1u) ymin = fmin(ymin, lds_sz[grp][t][lane][1]);
-            else smin = fmin(smin, s_slack(t, fx, fy));
+            if ((abits >> t) & 1u) { const double yt = lds_sz[grp][t][lane][1]; ymin = fmin(ymin, yt); ymax = fmax(ymax, yt); }
+            else { smin = fmin(smin, s_slack(t, fx, fy)); rbest = fmin(rbest, s_ratio(t, fx, fy, ddx, ddy)); }
           }
         }
       }
+      rbest = gmin<G>(rbest);
       ymin = gmin<G>(ymin);
-      smin = gmin<G>(smin);
-      int yi = 0x7fffffff, si = 0x7fffffff;
-      const double qabs = gmax<G>(fabs(qf));
-      const bool dropping = !fin_done & (ymin < -FIN_EPS);
-      const bool adding = !fin_done & !dropping & (smin < -FIN_EPS);
-      if (__any(dropping | adding)) {
+      int bi = 0x7fffffff;
+      const bool blocked = !fin_done & (rbest < 1.0);
+      const bool dropping = !fin_done & !blocked & (ymin < -FIN_EPS);
+      if (__any(blocked)) {                         // which row blocks: lowest canonical index among the rows at the minimum
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
           const int ci = ci_of(i);
-          const bool ta = act[i], ti = pres[i] & !ta;
-          yi = (ta & (y[i] == ymin) & (ci < yi)) ? ci : yi;
-          si = (ti & (slk[i] == smin) & (ci < si)) ? ci : si;
+          bi = ((rr[i] == rbest) & (ci < bi)) ? ci : bi;          // (rr is finite on candidates only)
         }
         if constexpr (STREAM) {
-          const double fx = cx_, fy = cy_;
 #pragma unroll STREAM_UNROLL
           for (int t = 0; t < NOBS_S; ++t) {
-            if ((pbits >> t) & 1u) {
+            if (((pbits >> t) & 1u) && !((abits >> t) & 1u)) {
               const int ci = ci_s(t);
-              if ((abits >> t) & 1u) {
-                if (lds_sz[grp][t][lane][1] == ymin && ci < yi) yi = ci;
-              } else if (s_slack(t, fx, fy) == smin && ci < si) si = ci;
+              if (s_ratio(t, fx, fy, ddx, ddy) == rbest && ci < bi) bi = ci;
             }
           }
         }
-        yi = gmin_int<G>(yi);
-        si = gmin_int<G>(si);
-        // register rows: drop / add by selects (the groups of a wave take different arms)
+        bi = gmin_int<G>(bi);
+      }
+      if (__any(blocked | dropping)) {
+        // register rows by selects (the groups of a wave take different arms): the blocking row joins; every row with a
+        // negative multiplier leaves
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-          const int ci = ci_of(i);
-          const bool hd = dropping & act[i] & (ci == yi), ha = adding & pres[i] & !act[i] & (ci == si);
+          const bool hd = dropping & act[i] & (y[i] < -FIN_EPS), ha = blocked & pres[i] & !act[i] & (ci_of(i) == bi);
           y[i] = hd ? 0.0 : y[i];
           act.m = (act.m & ~((unsigned)hd << i)) | ((unsigned)ha << i);
         }
+        if constexpr (STREAM) {
+#pragma unroll STREAM_UNROLL
+          for (int t = 0; t < NOBS_S; ++t) {
+            const bool on_t = (pbits >> t) & 1u, act_t = (abits >> t) & 1u;
+            if (dropping && act_t && lds_sz[grp][t][lane][1] < -FIN_EPS) { abits &= ~(1u << t); lds_sz[grp][t][lane][1] = 0.0; }
+            if (blocked && on_t && !act_t && ci_s(t) == bi) abits |= 1u << t;
+          }
+        }
       }
       if (!fin_done) {
-        if (ymin < -FIN_EPS) {
-          if constexpr (STREAM) {
-#pragma unroll STREAM_UNROLL
-            for (int t = 0; t < NOBS_S; ++t)
-              if (((abits >> t) & 1u) && ci_s(t) == yi) { abits &= ~(1u << t); lds_sz[grp][t][lane][1] = 0.0; }
-          }
-        } else if (smin < -FIN_EPS) {
-          if constexpr (STREAM) {
-#pragma unroll STREAM_UNROLL
-            for (int t = 0; t < NOBS_S; ++t)
-              if (((pbits >> t) & 1u) && !((abits >> t) & 1u) && ci_s(t) == si) abits |= 1u << t;
-          }
+        if (blocked) {
+          xf = fma(rbest, dd, xf);
         } else {
-          fin_done = true;
-          certified = fok && (eres <= FIN_EPS) && (qabs < 1e300);
-          diag_cert = fmin(ymin, smin);      // how decisively the certificate holds (weakly active rows -> ~0)
+          xf = qf;
+          // polish: an equality solve left above FIN_POLISH_TOL (two active rows a few 1e-6 from parallel: the multiplier
+          // iteration contracts that direction by 2 / (2 + rho sigma^2) per correction only) gets one more round on the
+          // same set at the stiffer penalty before it may certify
+          const bool polish = !dropping & (eres > FIN_POLISH_TOL) & (rho == FIN_RHO) & (rnd + 1 < P.fin_rounds);
+          rho = polish ? FIN_RHO_POLISH : rho;
+          if (!dropping && !polish) {
+            ymax = gmax<G>(ymax);
+            smin = gmin<G>(smin);
+            const double qabs = gmax<G>(fabs(qf));
+            fin_done = true;
+            certified = fok && (r_g <= FIN_EPS) && (rd_g <= FIN_EPS + FIN_DUAL_REL * ymax) && (smin >= -FIN_EPS) && (qabs < 1e300);
+            diag_cert = fmin(ymin, smin);      // how decisively the certificate holds (weakly active rows -> ~0)
+          }
         }
         diag_rounds = rnd + 1;
         diag_eres = eres;
@@ -1284,7 +1327,7 @@ __device__ __forceinline__ StepOut step_body(
     }
     if (ipm_ok) {
       if (certified) {
-        q = qf;
+        q = xf;
       } else {
         status = LIPMPC_STATUS_UNCERTIFIED;
 #pragma unroll
@@ -1361,7 +1404,7 @@ __global__ __launch_bounds__(WAVE) void plan_step_kernel(
     double* __restrict__ omega_out, double* __restrict__ obj_out, int32_t* __restrict__ status_out,
     int32_t* __restrict__ iters_out, unsigned long long* __restrict__ active_out, double* __restrict__ c_eta,
     double* __restrict__ diag, const double* __restrict__ bounds, const double* __restrict__ c_eta_in,
-    int32_t* __restrict__ sched) {
+    int32_t* __restrict__ sched, const int32_t* __restrict__ overflow_in) {
   constexpr int GPW = WAVE / G;
   static_assert(G == 16 || G == 32, "a problem is one or two DPP rows of one wavefront");
   if (blockDim.x != WAVE) __builtin_trap();          // wave_sync() and every group exchange assume a one-wave workgroup
@@ -1385,6 +1428,7 @@ __global__ __launch_bounds__(WAVE) void plan_step_kernel(
   in.gx = goal[pb * 2 + 0]; in.gy = goal[pb * 2 + 1];
   in.foot0 = (double)first_foot[pb];
   in.delta = delta_in ? delta_in[pb] : 0.0;
+  in.sensor_overflow = overflow_in && overflow_in[pb] != 0;
   step_body<G, NOBS_L, NVAR>(P, in, obs_xy, obs_nv, U, X, theta_out, omega_out, obj_out, status_out, iters_out, active_out,
                              c_eta, diag, c_eta_in, nullptr, sched ? sched + SCHED_ORDER + B : nullptr);
 }
@@ -1479,7 +1523,7 @@ void launch_plan_step(const KArgs& k, long B, const double* state, const double*
                       const double* delta, const double* obs_xy, const int32_t* obs_nv, double* U, double* X,
                       double* theta, double* omega, double* obj, int32_t* status, int32_t* iters,
                       unsigned long long* active, double* c_eta, double* diag, const double* bounds,
-                      const double* c_eta_in, int32_t* sched, hipStream_t stream);
+                      const double* c_eta_in, int32_t* sched, const int32_t* overflow_in, hipStream_t stream);
 template <int G, int NOBS_L, int NVAR>
 void launch_rollout(const KArgs& k, long B, int k_max, int mpc_step, double stop_obj, const double* state0,
                     const double* goal, const int8_t* first_foot, const double* delta, const double* obs_xy,

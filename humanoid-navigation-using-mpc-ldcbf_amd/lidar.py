@@ -73,8 +73,11 @@ class LidarSensor:
         the dict carries c_eta [B,n_obs_max,4] = (c, eta) of every inferred hull at the robot's CoM -- what
         ``BatchedLipMpc.plan_step_batch_c_eta`` solves against; with ``rings=False`` the hulls never leave the kernel.
         ``schedule``: a buffer of ``make_schedule(B)``, None (robots in index order), or "auto" (default): with
-        ``c_eta=True`` the sensor keeps one schedule per batch size, so repeated scans of a batch start their robots
-        heaviest first by the previous scan's reading counts (a scheduling hint only: results never depend on it).
+        ``c_eta=True`` the sensor keeps one schedule per (batch size, current stream), so repeated scans of a batch start
+        their robots heaviest first by the previous scan's reading counts.  A scheduling hint only -- any order gives the same
+        results -- but scans that share a schedule BUFFER must be ordered on one stream (the order kernel of one launch
+        rewrites what the next launch reads; a torn order would scan some robots twice and others not at all): a buffer
+        of ``make_schedule`` handed to launches on two streams, or to two graphs replayed concurrently, is a caller's bug.
         Vertex slots beyond obs_nv keep whatever an earlier call left there when ``out`` is reused.
         ``env_xy`` [B,n_env,v_env,2] / ``env_nv`` [B,n_env] (device tensors): one true map PER ROBOT instead of the
         sensor's shared map (env_shared = 0 of the C ABI)."""
@@ -110,10 +113,13 @@ class LidarSensor:
                 raise ValueError('schedule: a make_schedule(B) buffer, None or "auto"')
             schedule = None
             if want_ce and B > 2048:                         # beyond one round of waves (two per SIMD) the start order matters
+                # one buffer per (batch size, stream): scans sharing a schedule must be ordered on one stream -- the order
+                # kernel of one launch rewrites what the next one reads
                 cache = self.__dict__.setdefault("_auto_sched", {})
-                if B not in cache:
-                    cache[B] = self.make_schedule(B)
-                schedule = cache[B]
+                key = (B, stream)
+                if key not in cache:
+                    cache[key] = self.make_schedule(B)
+                schedule = cache[key]
         if schedule is not None and (not want_ce or schedule.dtype != torch.int32 or schedule.device != dev or not schedule.is_contiguous()
                                      or schedule.numel() != int(self.lib.lipmpc_lidar_schedule_words(B))):
             raise ValueError("schedule: a buffer of make_schedule(B) for this B, with c_eta=True")

@@ -12,7 +12,7 @@ import torch
 from . import _lib
 
 STATUS_SOLVED, STATUS_MAX_ITER, STATUS_INFEASIBLE, STATUS_DEGENERATE, STATUS_UNCERTIFIED = 0, 1, 2, 3, 4
-STATUS_SENSOR_OVERFLOW = 5     # fleet loop only: a scan's clusters did not fit the obstacle slots
+STATUS_SENSOR_OVERFLOW = 5     # a scan's clusters did not fit the obstacle slots: not solved (sense_plan_step, plan_step_batch_c_eta(overflow=)), robot stopped (fleet loop)
 FLAG_INTERIOR = 1
 FLAG_WARM_START = 2      # rollout: start every step from the previous step's shifted interior-point result
 
@@ -25,7 +25,7 @@ class LipMpcParams:
     n_obs_max: int = 0
     v_max: int = 5
     max_iter: int = 60
-    finish_rounds: int = 0      # 0 = library default (5 add/drop rounds for N <= 8, else 10)
+    finish_rounds: int = 0      # 0 = library default (8 active-set rounds for N <= 8, else 16)
     flags: int = 0
     dt: float = 0.4
     g: float = 9.81
@@ -158,23 +158,28 @@ class BatchedLipMpc:
         _lib.check(rc, "lipmpc_plan_step_batch")
         return out
 
-    def plan_step_batch_c_eta(self, state, goal, first_foot, c_eta_in, delta=None, out=None, with_diag=False, bounds=None):
+    def plan_step_batch_c_eta(self, state, goal, first_foot, c_eta_in, delta=None, out=None, with_diag=False, bounds=None,
+                              overflow=None):
         """The step with the LDCBF half-spaces given (lipmpc_plan_step_batch_c_eta): c_eta_in [B,n_obs_max,4] =
         (c_x, c_y, eta_x, eta_y) per slot, eta = (0,0) = empty slot; row j of stage k is eta_j.(p_k - c_j) - delta >= 0.
-        This is what a subclass overriding the reference's _get_list_c_and_eta / _compute_single_lcbf hooks feeds."""
+        This is what a subclass overriding the reference's _get_list_c_and_eta / _compute_single_lcbf hooks feeds.
+        overflow [B] int32 or None: the flags of whoever produced the rows (LidarSensor.sense: the scan's clusters did not fit
+        the obstacle slots); a flagged problem is not solved against its truncated list: status STATUS_SENSOR_OVERFLOW, NaN
+        outputs (advance() leaves the robot where it is)."""
         P = self.params
         B = self._check_inputs(state, goal, first_foot, None, None, delta, need_obstacles=False)
         if (c_eta_in is None or tuple(c_eta_in.shape) != (B, P.n_obs_max, 4) or c_eta_in.dtype != torch.float64
                 or c_eta_in.device != self.device or not c_eta_in.is_contiguous()):
             raise ValueError(f"c_eta_in: expected contiguous float64 {(B, P.n_obs_max, 4)} on {self.device}")
         self._check_optional(bounds, (B, 4), torch.float64, "bounds")
+        self._check_optional(overflow, (B,), torch.int32, "overflow")
         if out is None:
             out = self.alloc_outputs(B, False, with_diag)
         else:
             self._check_outputs(out, B)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = self.lib.lipmpc_plan_step_batch_c_eta(
-            self._h, B, _ptr(state), _ptr(goal), _ptr(first_foot), _ptr(delta), _ptr(c_eta_in),
+            self._h, B, _ptr(state), _ptr(goal), _ptr(first_foot), _ptr(delta), _ptr(c_eta_in), _ptr(overflow),
             _ptr(out["U"]), _ptr(out["X"]), _ptr(out["theta"]), _ptr(out["omega"]), _ptr(out["obj"]),
             _ptr(out["status"]), _ptr(out["iters"]), _ptr(out["active"]), _ptr(out.get("diag")), _ptr(bounds),
             C.c_void_p(stream))

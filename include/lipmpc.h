@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define LIPMPC_ABI_VERSION 3   /* 2: + lipmpc_plan_step_batch_c_eta, LIPMPC_STATUS_SENSOR_OVERFLOW; 3: + lipmpc_lidar_c_eta_batch */
+#define LIPMPC_ABI_VERSION 4   /* 2: + lipmpc_plan_step_batch_c_eta, LIPMPC_STATUS_SENSOR_OVERFLOW; 3: + lipmpc_lidar_c_eta_batch;
+                                * 4: lipmpc_plan_step_batch_c_eta takes the producer's overflow flags */
 
 /* per-problem status written to status[b] */
 #define LIPMPC_STATUS_SOLVED       0  /* exact optimum, KKT-certified active set */
@@ -37,10 +38,11 @@ extern "C" {
                                          the reference raises inside solve() here (HumanoidMpc.py:419-429) */
 #define LIPMPC_STATUS_DEGENERATE   3  /* x == c or zero-length edge: reference yields NaN (ObstaclesUtils.py:81,104) */
 #define LIPMPC_STATUS_UNCERTIFIED  4  /* interior-point tolerance met, active-set finish not certified */
-#define LIPMPC_STATUS_SENSOR_OVERFLOW 5 /* written by lipmpc_fleet_update_batch only (last_status): the sample's inferred
-                                         obstacles did not fit the slots (overflow[b] != 0), the robot is stopped rather
-                                         than planned against a truncated obstacle list -- the reference constrains
-                                         against every inferred obstacle, HumanoidMPCUnknownEnvironment.py:55-64 */
+#define LIPMPC_STATUS_SENSOR_OVERFLOW 5 /* the sample's inferred obstacles did not fit the slots (overflow[b] != 0): the step is not
+                                         solved (lipmpc_plan_step_batch_c_eta with overflow flags, lipmpc_sense_plan_step_batch)
+                                         and the robot is stopped (lipmpc_fleet_update_batch) rather than planned against a
+                                         truncated obstacle list -- the reference constrains against every inferred obstacle,
+                                         HumanoidMPCUnknownEnvironment.py:55-64 */
 
 /* flags */
 #define LIPMPC_FLAG_INTERIOR 1  /* skip the active-set finish: return the strictly interior
@@ -65,8 +67,8 @@ typedef struct lipmpc_params {
   int32_t v_max;        /* vertex slots per obstacle ring, 3..32 */
   int32_t max_iter;     /* interior-point iteration cap */
   int32_t flags;        /* LIPMPC_FLAG_* */
-  int32_t finish_rounds; /* cap on the add/drop rounds of the certified active-set finish (tail-latency control:
-                           a problem that needs more ends UNCERTIFIED with the interior-point answer); 0 = default (5 for N <= 8, else 10) */
+  int32_t finish_rounds; /* cap on the rounds of the certified active-set finish (tail-latency control:
+                           a problem that needs more ends UNCERTIFIED with the interior-point answer); 0 = default (8 for N <= 8, else 16) */
   double dt;            /* DELTA_T            config.yml:2  */
   double g;             /* GRAVITY_CONST      config.yml:3  */
   double h_com;         /* COM_HEIGHT         config.yml:4  */
@@ -141,11 +143,15 @@ int64_t lipmpc_schedule_words(int64_t B);
  * HumanoidMPCCustomLCBF.py:30-31) as data.  Row j of every stage k is  eta_j . (p_k - c_j) - delta >= 0  with
  *  c_eta_in [B,n_obs_max,4] (c_x, c_y, eta_x, eta_y); eta need not be a unit vector; eta = (0,0) marks an empty slot,
  *  a NaN in eta marks degenerate geometry met by whoever produced the row (status DEGENERATE, as the ring front end gives).
+ *  overflow [B] int32 or NULL: the producer's "obstacles were dropped" flags (lipmpc_lidar_c_eta_batch: the scan's clusters
+ *  did not fit the obstacle slots).  A flagged problem is NOT solved against its truncated list -- the reference constrains
+ *  against every inferred obstacle (HumanoidMPCUnknownEnvironment.py:55-64) -- it gets status SENSOR_OVERFLOW and NaN
+ *  outputs, so lipmpc_advance_batch and every other consumer of `status` leave the robot where it is.
  * Nothing of the geometry front end runs; the constant k = 0 row is still checked against k0_tol.
  * Outputs as lipmpc_plan_step_batch (without c_eta). */
 int lipmpc_plan_step_batch_c_eta(lipmpc_handle* h, int64_t B,
                                  const double* state, const double* goal, const int8_t* first_foot,
-                                 const double* delta, const double* c_eta_in,
+                                 const double* delta, const double* c_eta_in, const int32_t* overflow,
                                  double* U, double* X, double* theta, double* omega, double* obj,
                                  int32_t* status, int32_t* iters, uint64_t* active, double* diag,
                                  const double* bounds, void* hip_stream);
@@ -246,7 +252,8 @@ int64_t lipmpc_lidar_schedule_words(int64_t B);
 /* One MPC step of the unknown-environment variant in ONE call (what HumanoidMPCUnknownEnvironment does per step,
  * HumanoidMPCUnknownEnvironment.py:30-68 + HumanoidMpc.py:387-418): lipmpc_lidar_c_eta_batch (scan, clusters, hulls,
  * closest point / normal: one launch, n_obs_max / v_max from the handle) followed on the same stream by
- * lipmpc_plan_step_batch_c_eta against those half-spaces.  c_eta [B,n_obs_max,4] is the hand-over buffer (and an output);
+ * lipmpc_plan_step_batch_c_eta against those half-spaces and the scan's overflow flags (a robot whose scan overflowed gets
+ * status SENSOR_OVERFLOW, not a plan).  c_eta [B,n_obs_max,4] is the hand-over buffer (and an output);
  * schedule as in lipmpc_lidar_c_eta_batch or NULL; every other argument as in the two functions. */
 int lipmpc_sense_plan_step_batch(lipmpc_handle* h, int64_t B, int32_t resolution, int32_t n_env, int32_t v_env,
                                  int32_t env_shared, double lidar_range, double eps, int32_t min_samples,

@@ -38,7 +38,8 @@ static const double IPM_STALL_TOL = 1e-6;
 static const int IPM_SLOW_FROM = 8;
 static const double IPM_SLOW_RATIO = 0.9, IPM_SLOW_SIGMA = 0.5;   /* no-progress safeguard, see lipmpc_oracle.py */
 static const double FIN_RHO = 1e10, FIN_EPS = 1e-9, FIN_INNER_TOL = 1e-11, FIN_IDENT = 1e5, FIN_STALL = 0.5;
-enum { FIN_ROUNDS = 5, FIN_ROUNDS_LONG = 10, FIN_INNER = 6 };
+static const double FIN_GD_MIN = 1e-14, FIN_DUAL_REL = 1e-14, FIN_RHO_POLISH = 1e12, FIN_POLISH_TOL = 1e-10;
+enum { FIN_ROUNDS = 8, FIN_ROUNDS_LONG = 16, FIN_INNER = 6 };
 
 /* ---- geometry (ObstaclesUtils.py:50-109) ------------------------------------------------ */
 static void closest_point_normal(const double* ring, int nv, double px, double py, double* cx, double* cy,
@@ -356,49 +357,73 @@ static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, cons
   double* y = W->y; double* slack = W->slack;
   for (int i = 0; i < m; ++i) act[i] = z[i] > FIN_IDENT * s[i];   /* under-estimate: see lipmpc_oracle.py */
   if (!(P->flags & LIPMPC_FLAG_INTERIOR)) {
-    double qf[NMAXV];
-    memcpy(qf, q, sizeof(double) * n);
+    /* primal active-set rounds from the interior-point iterate x (see finish_active_set in lipmpc_oracle.py):
+     * equality solve on A -> ratio test along d = x_A - x (a blocked step adds the blocking row) -> else drop the negative
+     * multipliers -> else certified */
+    double qf[NMAXV], xf[NMAXV], dd[NMAXV];
+    memcpy(xf, q, sizeof(double) * n);
     for (int i = 0; i < m; ++i) y[i] = act[i] ? z[i] : 0.0;
     int certified = 0, rounds = 0;
-    double eres = INFINITY;
+    double eres = INFINITY, rho = FIN_RHO;
     const int fin_rounds = P->finish_rounds > 0 ? P->finish_rounds : (P->N <= 8 ? FIN_ROUNDS : FIN_ROUNDS_LONG);
     for (int rnd = 1; rnd <= fin_rounds; ++rnd) {
       rounds = rnd;
-      for (int i = 0; i < m; ++i) d[i] = act[i] ? FIN_RHO : 0.0;
+      for (int i = 0; i < m; ++i) d[i] = act[i] ? rho : 0.0;
       form_K(G, d, m, n, K);
       int fok = cholesky(K, n);
+      memcpy(qf, xf, sizeof(double) * n);
       eres = INFINITY;
+      double rdmax = 0.0, rmax = 0.0;
       for (int in = 0; in <= FIN_INNER; ++in) {
         mat_vec(G, qf, m, n, t);
-        double rmax = 0.0;
+        rmax = 0.0;
         for (int i = 0; i < m; ++i) { w[i] = act[i] ? (t[i] - h[i]) : 0.0; rmax = fmax(rmax, fabs(w[i])); }
         matT_vec(G, y, m, n, rd);
-        double rdmax = 0.0;
+        rdmax = 0.0;
         for (int i = 0; i < n; ++i) { rd[i] += 2.0 * (qf[i] - g[i]); rdmax = fmax(rdmax, fabs(rd[i])); }
         const double eprev = eres;
         eres = fmax(rdmax, rmax);
         if (eres <= FIN_INNER_TOL || in == FIN_INNER || (eres <= FIN_EPS && eres > FIN_STALL * eprev)) break;
-        for (int i = 0; i < m; ++i) rc[i] = FIN_RHO * w[i];
+        for (int i = 0; i < m; ++i) rc[i] = rho * w[i];
         matT_vec(G, rc, m, n, tmp);
         for (int i = 0; i < n; ++i) dq[i] = -rd[i] - tmp[i];
         chol_solve(K, n, dq);
         mat_vec(G, dq, m, n, ds);
         for (int i = 0; i < n; ++i) qf[i] += dq[i];
-        for (int i = 0; i < m; ++i) if (act[i]) y[i] += FIN_RHO * (ds[i] + w[i]);
+        for (int i = 0; i < m; ++i) if (act[i]) y[i] += rho * (ds[i] + w[i]);
       }
-      mat_vec(G, qf, m, n, t);
-      double ymin = INFINITY, smin = INFINITY;
-      int yi = -1, si = -1;
+      /* (t holds G qf: every pass of the loop above evaluates it before it decides to stop) */
+      for (int i = 0; i < n; ++i) dd[i] = qf[i] - xf[i];
+      mat_vec(G, dd, m, n, ds);                          /* g_i . d */
+      double rbest = INFINITY;
+      int blk = -1;
       for (int i = 0; i < m; ++i) {
-        slack[i] = h[i] - t[i];
-        if (act[i]) { if (y[i] < ymin) { ymin = y[i]; yi = i; } }
-        else if (slack[i] < smin) { smin = slack[i]; si = i; }
+        slack[i] = h[i] - t[i];                           /* slack at x_A */
+        if (!act[i] && ds[i] > FIN_GD_MIN) {
+          const double r = fmax(slack[i] + ds[i], 0.0) / ds[i];     /* slack at x over the approach rate */
+          if (r < rbest) { rbest = r; blk = i; }
+        }
       }
-      if (yi >= 0 && ymin < -FIN_EPS) { act[yi] = 0; y[yi] = 0.0; continue; }
-      if (si >= 0 && smin < -FIN_EPS) { act[si] = 1; continue; }
+      if (blk >= 0 && rbest < 1.0) {
+        for (int i = 0; i < n; ++i) xf[i] += rbest * dd[i];
+        act[blk] = 1;
+        continue;
+      }
+      memcpy(xf, qf, sizeof(double) * n);
+      double ymin = INFINITY, ymax = 0.0, smin = INFINITY;
+      for (int i = 0; i < m; ++i) {
+        if (act[i]) { ymin = fmin(ymin, y[i]); ymax = fmax(ymax, y[i]); }
+        else smin = fmin(smin, slack[i]);
+      }
+      if (ymin < -FIN_EPS) {                             /* every negative multiplier leaves at once */
+        for (int i = 0; i < m; ++i) if (act[i] && y[i] < -FIN_EPS) { act[i] = 0; y[i] = 0.0; }
+        continue;
+      }
+      /* polish: an equality solve left above FIN_POLISH_TOL gets one more round on the same set at the stiffer penalty */
+      if (eres > FIN_POLISH_TOL && rho == FIN_RHO && rnd < fin_rounds) { rho = FIN_RHO_POLISH; continue; }
       double qmax = 0.0;
       for (int i = 0; i < n; ++i) qmax = fmax(qmax, fabs(qf[i]));
-      certified = fok && eres <= FIN_EPS && qmax < 1e300;
+      certified = fok && rmax <= FIN_EPS && rdmax <= FIN_EPS + FIN_DUAL_REL * ymax && smin >= -FIN_EPS && qmax < 1e300;
       if (diag) diag[3] = fmin(ymin, smin);
       break;
     }

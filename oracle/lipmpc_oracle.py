@@ -347,12 +347,16 @@ IPM_SLOW_SIGMA = 0.5   # ... then centre at least 0 .. this much, linearly (brea
                        # a ramp, not a switch: a threshold would let two implementations part ways on a rounding)
 FIN_RHO = 1e10         # penalty of the active-set equality solve
 FIN_EPS = 1e-9         # sign / violation threshold of the certificate
-FIN_ROUNDS = 5         # default cap on add/drop rounds (Params.finish_rounds = 0) for N <= 8
-FIN_ROUNDS_LONG = 10   # ... and for longer horizons
+FIN_ROUNDS = 8         # default cap on active-set rounds (Params.finish_rounds = 0) for N <= 8
+FIN_ROUNDS_LONG = 16   # ... and for longer horizons
 FIN_IDENT = 1e5        # initial working set: z_i > FIN_IDENT * s_i (see finish_active_set)
 FIN_INNER = 6          # max multiplier iterations per equality solve
 FIN_INNER_TOL = 1e-11
 FIN_STALL = 0.5        # a correction that leaves more than this share of the residual has stalled (stop if already <= FIN_EPS)
+FIN_RHO_POLISH = 1e12  # penalty of the polish round (see finish_active_set, 5.)
+FIN_POLISH_TOL = 1e-10 # an equality solve left above this is polished before it may certify
+FIN_GD_MIN = 1e-14     # ratio test: a direction component below this does not run into its row
+FIN_DUAL_REL = 1e-14   # stationarity tolerance of the certificate: FIN_EPS + this x largest multiplier (rounding floor of G_A^T y)
 WARM_Z_MIN, WARM_Z_MAX = 3.0, 100.0   # warm start of a closed loop: previous multipliers, shifted by one stage, clipped to this band
 
 
@@ -431,70 +435,107 @@ def _max_step(v, dv):
     return float(np.min(-v[neg] / dv[neg]))
 
 
-def eqp_multiplier_method(G, h, g, active, q, y_full):
+def eqp_multiplier_method(G, h, g, active, q, y_full, rho=None):
     """min |q-g|^2 s.t. G_A q = h_A by the method of multipliers in residual-correction form,
-    warm-started at the IPM point: K_A = 2I + rho G_A^T G_A (one Cholesky), then repeat
+    warm-started at the current point: K_A = 2I + rho G_A^T G_A (one Cholesky), then repeat
       rd = 2(q-g) + G_A^T y ; r = G_A q - h_A ; dq = -K_A^{-1}(rd + rho G_A^T r) ;
       q += dq ; y += rho (G_A dq + r)
-    until max(|rd|,|r|) <= 1e-11 (at most 6 times, or until a correction stalls below 1e-9).  Dependent active rows are harmless."""
+    until max(|rd|,|r|) <= 1e-11 (at most 6 times, or until a correction stalls below 1e-9).  Dependent active rows are
+    harmless.  Returns q, y, max|rd|, max|r| of the last evaluation."""
     n = G.shape[1]
+    rho = FIN_RHO if rho is None else rho
     GA, hA = G[active], h[active]
     y = y_full[active].copy()
     q = q.copy()
     if GA.shape[0] == 0:
-        return g.copy(), y, 0.0
-    K = 2.0 * np.eye(n) + FIN_RHO * GA.T @ GA
+        return g.copy(), y, 0.0, 0.0
+    K = 2.0 * np.eye(n) + rho * GA.T @ GA
     L = np.linalg.cholesky(K)
     res = math.inf
     for _ in range(FIN_INNER + 1):
         rd = 2.0 * (q - g) + GA.T @ y
         r = GA @ q - hA
         prev = res
-        res = max(float(np.max(np.abs(rd))), float(np.max(np.abs(r))))
+        rdmax, rmax = float(np.max(np.abs(rd))), float(np.max(np.abs(r)))
+        res = max(rdmax, rmax)
         # converged, out of corrections, or stalled on its rounding floor below what the certificate needs (FIN_EPS)
         if res <= FIN_INNER_TOL or _ == FIN_INNER or (res <= FIN_EPS and res > FIN_STALL * prev):
             break
-        dq = np.linalg.solve(L.T, np.linalg.solve(L, -rd - FIN_RHO * (GA.T @ r)))
+        dq = np.linalg.solve(L.T, np.linalg.solve(L, -rd - rho * (GA.T @ r)))
         q = q + dq
-        y = y + FIN_RHO * (GA @ dq + r)
-    return q, y, res
+        y = y + rho * (GA @ dq + r)
+    return q, y, rdmax, rmax
 
 
 def finish_active_set(G, h, g, res: QPResult, rounds_cap: int = 0):
-    """Turn the interior-point estimate into the exact minimiser with a KKT certificate.
-    Working set A <- {i : z_i > 1e5 s_i}; solve the equality-constrained problem on A; if some
-    multiplier is < -1e-9 drop the most negative one, else if some row outside A is violated
-    by more than 1e-9 add the most violated one; repeat (<= 10 rounds).  The initial set is a
-    deliberate UNDER-estimate (only rows with a substantial multiplier): a missing row shows up
-    as an unambiguous violation and is added in one round, whereas a wrongly included, nearly
-    degenerate row (the CoM sliding along one obstacle's half-plane over several stages) makes
-    the multipliers of the equality solve non-unique and their signs unreliable.  When neither happens
-    (and the equality solve converged to 1e-9) the point satisfies primal feasibility, dual
-    feasibility and complementarity, i.e. it is the unique optimum of the strictly convex QP."""
+    """Turn the interior-point estimate into the exact minimiser with a KKT certificate: a PRIMAL active-set method
+    started at the interior-point iterate x (feasible to the IPM's 1e-11) on the working set A <- {i : z_i > 1e5 s_i}.
+    Per round (one factorisation of K_A):
+      1. x_A = minimiser on the working set (equality solve above, warm-started at x);
+      2. ratio test along d = x_A - x over the rows outside A that d runs into (g_i.d > FIN_GD_MIN):
+         alpha = min_i max(slack_i(x), 0) / g_i.d.  If alpha < 1 the step is BLOCKED: x <- x + alpha d, the blocking row
+         (lowest canonical index among ties) joins A; next round;
+      3. otherwise x <- x_A; the rows of A whose multiplier is < -1e-9 leave A, all of them at once (any subset may leave
+         without losing feasibility or descent -- the minimiser on a smaller set is no worse -- and rows that are needed
+         after all come back through the ratio test; one at a time the worst problem of the bench batch took 8 rounds, so 5);
+         next round;
+      4. otherwise x is feasible with non-negative multipliers: the unique optimum of the strictly convex QP -- certified
+         when the equality solve met the tolerances (constraint residual 1e-9; stationarity 1e-9 + FIN_DUAL_REL x the largest
+         multiplier: the residual 2(q-g) + G_A^T y cannot be evaluated below the rounding of its own terms, which grow
+         with y -- IPOPT scales its dual infeasibility by the multiplier size in the same way);
+      5. ... after a POLISH round where the equality solve was left above FIN_POLISH_TOL: the multiplier iteration contracts
+         the error along a singular direction sigma of G_A by 2 / (2 + rho sigma^2) per correction, so two active rows within
+         1e-5 of parallel (sigma ~ 6e-6: rho sigma^2 = 0.4 at rho = 1e10) leave the vertex 2e-6 off after the six
+         corrections of a round -- measured against a 40-digit solve of the same working set -- while the residuals
+         already read 3e-9.  Such a round (3 % of the N = 16 / 50-obstacle problems, 0.3 % at N = 8 / 10) is followed by one
+         at rho = FIN_RHO_POLISH on the same set: 1e-11 from the 40-digit vertex.
+    x stays feasible and the objective never increases, so the rounds cannot wander: a blocked step never crosses a row, and a
+    blocking row is never (nearly) dependent on A -- g_i.d = 0 for every row in the span of A, d being in A's null space -- so
+    the working set stays independent where the add-the-most-violated / drop-the-most-negative exchange of rounds 1-2
+    cycled through the dependent rows of degenerate vertices (1.1-1.6 % of the N = 16 / 50-obstacle problems uncertified after
+    10 rounds, some after 64; the ratio-test rounds certify all 4096 of them within 10).  The initial set is a deliberate
+    UNDER-estimate (rows with a substantial multiplier): a wrongly included, nearly degenerate row makes the
+    multipliers of the first equality solve non-unique and their signs unreliable."""
     m = G.shape[0]
     nz = np.any(G != 0.0, axis=1)
     A = (res.z > FIN_IDENT * res.s) & nz
-    q, yf = res.q, np.where(A, res.z, 0.0)
+    x, yf = res.q.copy(), np.where(A, res.z, 0.0)
     cap = rounds_cap if rounds_cap > 0 else FIN_ROUNDS
+    rho = FIN_RHO
     for rnd in range(1, cap + 1):
-        q, y, eres = eqp_multiplier_method(G, h, g, A, q, yf)
+        try:
+            xw, y, rdmax, rmax = eqp_multiplier_method(G, h, g, A, x, yf, rho)
+        except np.linalg.LinAlgError:                      # K_A not numerically positive definite at this penalty
+            return x, yf, None, A, rnd, None
         yf = np.zeros(m); yf[A] = y
-        slack = h - G @ q
-        ymin_i = int(np.argmin(np.where(A, yf, math.inf)))
-        smin_i = int(np.argmin(np.where(~A & nz, slack, math.inf)))
-        if A.any() and yf[ymin_i] < -FIN_EPS:
-            A[ymin_i] = False
-            yf[ymin_i] = 0.0
+        slack_w = h - G @ xw
+        d = xw - x
+        gd = G @ d
+        sl = slack_w + gd                                  # slack at x
+        cand = ~A & nz & (gd > FIN_GD_MIN)
+        if cand.any():
+            ratio = np.where(cand, np.maximum(sl, 0.0) / np.where(cand, gd, 1.0), math.inf)
+            blk = int(np.argmin(ratio))                    # ties: lowest canonical index
+            if ratio[blk] < 1.0:
+                x = x + ratio[blk] * d
+                A[blk] = True
+                continue
+        x = xw
+        neg = A & (yf < -FIN_EPS)
+        if neg.any():                                      # every negative multiplier leaves at once
+            A = A & ~neg
+            yf[neg] = 0.0
             continue
-        if (~A & nz).any() and slack[smin_i] < -FIN_EPS:
-            A[smin_i] = True
+        if max(rdmax, rmax) > FIN_POLISH_TOL and rho == FIN_RHO and rnd < cap:
+            rho = FIN_RHO_POLISH                            # 5. polish: one more round on the same set, stiffer penalty
             continue
-        if eres <= FIN_EPS and np.all(np.isfinite(q)):
-            cert = min(float(np.min(yf[A])) if A.any() else math.inf,
-                       float(np.min(slack[~A & nz])) if (~A & nz).any() else math.inf)
-            return q, yf, slack, A, rnd, cert
-        break
-    return q, yf, None, A, cap, None
+        ymax = float(np.max(yf[A])) if A.any() else 0.0
+        smin = float(np.min(slack_w[~A & nz])) if (~A & nz).any() else math.inf
+        if rmax <= FIN_EPS and rdmax <= FIN_EPS + FIN_DUAL_REL * ymax and smin >= -FIN_EPS and np.all(np.isfinite(x)):
+            cert = min(float(np.min(yf[A])) if A.any() else math.inf, smin)
+            return x, yf, slack_w, A, rnd, cert
+        return x, yf, None, A, rnd, None
+    return x, yf, None, A, cap, None
 
 
 def solve_qp_exact(G, h, g, q0, tol=1e-11, max_iter=60, finish_rounds=0, z0=None):

@@ -6,6 +6,35 @@ import numpy as np
 import lipmpc_oracle as O
 
 
+CERT_MARGIN = 1e-8     # 10 x FIN_EPS, the sign / violation tolerance the certificate itself decides rows with
+
+
+def decisive_mask(ok, diag_a, diag_b, margin=CERT_MARGIN):
+    """Problems on which "active-constraint indices bit-exact" is well posed: certified on both sides (``ok``) with a
+    DECISIVE certificate on both sides -- diag[:, 3] = min(smallest multiplier on the active set, smallest slack outside
+    it) >= margin.  Then strict complementarity holds with room, the optimum's active set is unique and both solvers must
+    report the same bits; below the margin a weakly active row (multiplier ~ 0) or a redundant one (slack ~ 0 outside the
+    set: dependent rows of a degenerate vertex) may legitimately sit on either side.  The ONE filter used by the parity
+    tests and by bench.py's cpu_baseline check (report the margin, exclude weakly active instances)."""
+    return ok & (diag_a[:, 3] >= margin) & (diag_b[:, 3] >= margin)
+
+
+def record_parity(tag, info):
+    """Observed agreement figures of a GPU-vs-oracle comparison, merged into the JSON file LIPMPC_PARITY_RECORD names
+    (tools/parity_record.sh writes profiles/rNN_parity.json this way); without the variable: gpurun_out/parity_record.json."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.environ.get("LIPMPC_PARITY_RECORD") or os.path.join(root, "gpurun_out", "parity_record.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        rec = json.load(open(path)) if os.path.exists(path) else {}
+        rec[tag] = info
+        json.dump(rec, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
 def load_rings(path, idx=None):
     d = np.load(path)
     rings, nv = d["rings"], d["nv"]

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/lipmpc.h but not exported"
     assert set(names) == set(lipmpc._lib.EXPORTS)
-    assert lib.lipmpc_version() == 3
+    assert lib.lipmpc_version() == 4
     assert b"ok" == lib.lipmpc_strerror(0)
 
 

@@ -5,9 +5,10 @@
   config 3  B = 32768, N = 8,  10 obstacles: properties on every problem, C oracle on a 4096 sample, shard independence
   config 4  B = 4096,  N = 16, 50 obstacles: every problem against the C oracle, active sets bit for bit
 
-Bars: footsteps / CoM 1e-5 (north_star; observed ~1e-8), theta / omega 1e-12, statuses and active-constraint indices
-bit-exact on the decisive subset (identification margin >= 0.5 and certificate margin >= 1e-6 on both sides; the
-excluded share is printed and bounded)."""
+Bars: footsteps / CoM 1e-5 (north_star; observed ~1e-7), theta / omega 1e-12, statuses and active-constraint indices
+bit-exact on the decisive subset (certificate margin >= 1e-8 on both sides: helpers.decisive_mask, the filter bench.py
+uses too; the excluded share is bounded).  The bars sit a small margin below the observed figures, which every call
+records (helpers.record_parity -> profiles/r03_parity.json via tools/parity_record.sh)."""
 import os
 
 import numpy as np
@@ -18,8 +19,11 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 import lipmpc  # noqa: E402
 import lipmpc_oracle as O  # noqa: E402
-from helpers import (IPOPT_LIKE_TOL, PDF_RUNS, check_pdf_bars, load_rings, oracle_pdf_run, pdf_compare,  # noqa: E402
-                     pdf_scenario)
+from helpers import (IPOPT_LIKE_TOL, PDF_RUNS, check_pdf_bars, decisive_mask, load_rings, oracle_pdf_run,  # noqa: E402
+                     pdf_compare, pdf_scenario, record_parity)
+
+
+MIN_DECISIVE_CFG4 = 0.78      # share of the certified N = 16 / 50-obstacle problems whose certificate is decisive (observed 0.82: r03_parity.json)
 
 
 def _dev(a, dt):
@@ -62,7 +66,7 @@ def _oracle(P, b, idx=None, n_threads=16):
     return c_oracle.plan_step_batch(P, h(b["state"]), h(b["goal"]), h(b["foot"]), xy, nv, h(b["delta"]), n_threads=n_threads)
 
 
-def _compare_with_oracle(tag, P, g, ref, min_decisive, iters_bars=(0.97, 0.999), max_split=0.0005):
+def _compare_with_oracle(tag, P, g, ref, min_decisive, iters_bars=(0.97, 0.999), max_split=0.0005, min_status_equal=0.999):
     """statuses, footsteps, active sets; returns the observed agreement figures (also printed for the record).
     max_split: tolerated share of problems that one side solves and the other reports failed (a factorisation
     breakdown at cond K ~ 1e16 is decided by the last bit: observed 0 or 1 problem in 4096 at N = 8)."""
@@ -80,7 +84,7 @@ def _compare_with_oracle(tag, P, g, ref, min_decisive, iters_bars=(0.97, 0.999),
     assert np.max(np.abs(g["theta"] - ref["theta"])) < 1e-12 and np.max(np.abs(g["omega"] - ref["omega"])) < 1e-12
     both = solved_g & solved_r
     dit = np.abs(g["iters"][both] - ref["iters"][both])
-    decisive = ok & (g["diag"][:, 2] >= 0.5) & (ref["diag"][:, 2] >= 0.5) & (g["diag"][:, 3] >= 1e-6) & (ref["diag"][:, 3] >= 1e-6)
+    decisive = decisive_mask(ok, g["diag"], ref["diag"])
     act_g = lipmpc.unpack_active(g["active"], P.num_rows)
     act_r = lipmpc.unpack_active(ref["active"], P.num_rows)
     mism = int(np.sum(np.any(act_g[decisive] != act_r[decisive], axis=1)))
@@ -90,8 +94,12 @@ def _compare_with_oracle(tag, P, g, ref, min_decisive, iters_bars=(0.97, 0.999),
                 iters_equal=float((dit == 0).mean()), iters_within_1=float((dit <= 1).mean()), iters_max_diff=int(dit.max()),
                 decisive=float(decisive.sum() / max(ok.sum(), 1)), active_mismatch=mism,
                 active_mismatch_all_certified=mism_all)
+    info["bars"] = dict(min_decisive=min_decisive, iters_equal=iters_bars[0], iters_within_1=iters_bars[1], max_split=max_split,
+                        min_status_equal=min_status_equal, max_dU=1e-5, active_mismatch=0)
     print(tag, info)
+    record_parity(tag, info)
     assert mism == 0, (tag, info)                                          # active-constraint indices bit-exact
+    assert same.mean() >= min_status_equal, (tag, info)
     assert decisive.sum() >= min_decisive * ok.sum(), (tag, info)
     # iteration counts: equal on most problems, off by one where the last residual test sits on the tolerance; the odd
     # problem of the ill-conditioned tail (cond K ~ 1e15 in its last iterations) takes a few more on one side
@@ -99,21 +107,29 @@ def _compare_with_oracle(tag, P, g, ref, min_decisive, iters_bars=(0.97, 0.999),
     return info, ok
 
 
-def _check_uncertified(tag, P, b, g, tol=1e-5):
-    """An UNCERTIFIED answer is the interior-point iterate handed out as usable: under the default round cap it must lie
-    within 1e-5 of the certified optimum, which the oracle reaches when its finish may run 64 rounds."""
+def _check_uncertified(tag, P, b, g, tol=1e-5, max_frac=0.002):
+    """An UNCERTIFIED answer is the interior-point iterate handed out as usable: there may be at most max_frac of them, and
+    under the default round cap each must lie within tol of the certified optimum, which the oracle reaches when its finish
+    may run 64 rounds."""
     idx = np.where(g["status"] == 4)[0]
+    rec = dict(uncertified=int(len(idx)), frac=float(len(idx) / len(g["status"])), bars=dict(tol=tol, max_frac=max_frac))
     if len(idx) == 0:
         print(tag, "no UNCERTIFIED answers")
+        record_parity(tag + " / uncertified", rec)
         return 0, 0.0
     P64 = lipmpc.LipMpcParams(**{**P.__dict__, "finish_rounds": 64})
     ref = _oracle(P64, b, idx)
     cert = ref["status"] == 0
     du = np.max(np.abs(g["U"][idx][cert] - ref["U"][cert]), axis=(1, 2)) if cert.any() else np.zeros(0)
-    print(tag, f"UNCERTIFIED {len(idx)}: certified by the 64-round oracle {int(cert.sum())}, max |dU| {du.max() if len(du) else 0:.2e}")
-    assert cert.mean() >= 0.75, (tag, np.bincount(ref["status"], minlength=5))
-    assert du.max() <= tol, (tag, du.max())
-    return len(idx), float(du.max())
+    rec.update(certified_by_64_round_oracle=int(cert.sum()), max_dU_vs_certified_optimum=float(du.max()) if len(du) else None)
+    print(tag, rec)
+    record_parity(tag + " / uncertified", rec)
+    assert len(idx) <= max_frac * len(g["status"]), (tag, rec)
+    if len(idx) >= 8:
+        assert cert.mean() >= 0.75, (tag, np.bincount(ref["status"], minlength=5))
+    if len(du):
+        assert du.max() <= tol, (tag, du.max())
+    return len(idx), float(du.max()) if len(du) else 0.0
 
 
 def _properties(N, g, ok, c_eta, delta):
@@ -189,7 +205,7 @@ def test_config2_uncertified_answers_are_within_tolerance():
     torch.cuda.synchronize()
     g = {k: v.cpu().numpy() for k, v in out.items()}
     ref = _oracle(P, b)
-    _compare_with_oracle("config 2", P, g, ref, min_decisive=0.9)
+    _compare_with_oracle("config 2", P, g, ref, min_decisive=0.95, iters_bars=(0.98, 0.999))
     _check_uncertified("config 2", P, b, g)
     # A cap of ONE finish round (a caller's tail-latency choice, not the default) leaves ~10 % of the batch UNCERTIFIED,
     # and those answers are plain interior-point iterates: the stop test ignores the dual residual (cond K * eps on
@@ -199,7 +215,7 @@ def test_config2_uncertified_answers_are_within_tolerance():
     out1 = lipmpc.BatchedLipMpc(P1).plan_step_batch(b["state"], b["goal"], b["foot"], b["obs_xy"], b["obs_nv"], b["delta"], with_diag=True)
     torch.cuda.synchronize()
     g1 = {k: v.cpu().numpy() for k, v in out1.items()}
-    n1, worst1 = _check_uncertified("config 2, finish_rounds=1", P1, b, g1, tol=2e-2)
+    n1, worst1 = _check_uncertified("config 2, finish_rounds=1", P1, b, g1, tol=2e-2, max_frac=1.0)
     assert n1 > 100
 
 
@@ -229,7 +245,7 @@ def test_config3_batch_32768():
     idx = np.sort(np.random.default_rng(5).choice(B, 4096, replace=False))
     ref = _oracle(P, b, idx)
     gi = {k: v[idx] for k, v in g.items()}
-    _compare_with_oracle("config 3 (4096 sample)", P, gi, ref, min_decisive=0.9)
+    _compare_with_oracle("config 3 (4096 sample)", P, gi, ref, min_decisive=0.95, iters_bars=(0.98, 0.999))
     for world in (2, 4, 8):
         for rank in (0, world - 1):
             lo, hi = sharding.shard_bounds(B, rank, world)
@@ -289,16 +305,14 @@ def test_config4_full_size_against_c_oracle():
     g = {k: v.cpu().numpy() for k, v in out.items()}
     ref = _oracle(P, b)
     assert np.array_equal(g["c_eta"], ref["c_eta"])
-    info, ok = _compare_with_oracle("config 4", P, g, ref, min_decisive=0.3, iters_bars=(0.85, 0.97), max_split=0.001)
-    assert info["status_equal"] >= 0.97 and info["certified_both"] >= 0.9
-    # the few problems only one side solves: the GPU's answers among them are feasible trajectories (checked below with
-    # all the others), i.e. the oracle's INFEASIBLE there is its own Cholesky breaking down, not an infeasible step
-    # UNCERTIFIED at this size (measured: 65 of 4096 = 1.6 %, 56 of them certified by the 64-round oracle): degenerate
-    # vertices -- linearly dependent active rows, non-unique multipliers -- on which the add/drop finish wanders until
-    # its cap.  Their answers are interior-point iterates: within 3.1e-4 of the optimum in footstep space here
-    # (sqrt(m mu) on weakly active rows, x100 from positions to footsteps at N = 16), NOT within the 1e-5 of certified
-    # answers; status 4 says so.  finish_rounds = 64 certifies most of them at the price of the launch's tail.
-    _check_uncertified("config 4", P, b, g, tol=1e-3)
+    info, ok = _compare_with_oracle("config 4", P, g, ref, min_decisive=MIN_DECISIVE_CFG4, iters_bars=(0.88, 0.985), max_split=0.001,
+                                    min_status_equal=0.995)
+    assert info["certified_both"] >= 0.995
+    # UNCERTIFIED at this size: the primal active-set rounds of the finish (ratio test: a blocking row is never dependent
+    # on the working set) certify the degenerate vertices -- linearly dependent active rows, non-unique multipliers -- on
+    # which the add / drop exchange of rounds 1-2 wandered until its cap (1.1-2 % of this batch); what is left (observed: 2
+    # of 4096) must lie within the 1e-5 of certified answers
+    _check_uncertified("config 4", P, b, g, tol=1e-5, max_frac=0.002)
     _properties(N, g, np.isin(g["status"], (0, 4)), g["c_eta"], b["delta"].cpu().numpy())
 
 
@@ -321,4 +335,5 @@ def test_config4_reference_generated_fields(golden_dir):
     g = {k: v.cpu().numpy() for k, v in out.items()}
     ref = c_oracle.plan_step_batch(P, st, goal, foot, xy, nv, delta, n_threads=16)
     assert np.array_equal(g["c_eta"], ref["c_eta"])
-    _compare_with_oracle("config 4 (reference fields)", P, g, ref, min_decisive=0.3, iters_bars=(0.85, 0.97), max_split=0.004)
+    _compare_with_oracle("config 4 (reference fields)", P, g, ref, min_decisive=MIN_DECISIVE_CFG4, iters_bars=(0.85, 0.97), max_split=0.004,
+                         min_status_equal=0.99)

@@ -394,6 +394,47 @@ def test_gpu_more_clusters_than_slots(golden_dir):
 
 
 @pytest.mark.gpu
+def test_gpu_sensor_overflow_reaches_the_step_status(golden_dir):
+    """A scan whose clusters do not fit the obstacle slots must not hand out a usable-looking plan (the reference constrains
+    against every inferred obstacle, HumanoidMPCUnknownEnvironment.py:55-64): through the one-call step
+    (lipmpc_sense_plan_step_batch) and through sense() + plan_step_batch_c_eta(overflow=) the robot's status is
+    SENSOR_OVERFLOW, its outputs NaN, and lipmpc_advance_batch -- which looks at status only -- leaves it where it is;
+    a robot of the same batch whose scan fits is planned and advanced as usual."""
+    torch = pytest.importorskip("torch")
+    import lipmpc
+    posts = []
+    for k in range(6):                        # six separate posts around the origin: six clusters for ONE slot
+        a = 2 * np.pi * k / 6
+        c = np.array([1.0 * np.cos(a), 1.0 * np.sin(a)])
+        posts.append(c + 0.06 * np.array([[np.cos(t), np.sin(t)] for t in np.linspace(0, 2 * np.pi, 9)[:-1]]))
+    sensor = lipmpc.LidarSensor(posts, lidar_range=1.5, n_obs_max=1, v_max=32)
+    sv = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=3, n_obs_max=1, v_max=32))
+    st = torch.zeros((2, 5), dtype=torch.float64, device="cuda"); st[1, 0] = 2.3          # robot 1 sees one post only
+    goal = torch.tensor([[5.0, 0.3]] * 2, dtype=torch.float64, device="cuda")
+    foot = torch.ones((2,), dtype=torch.int8, device="cuda")
+    noise = 0.01 * torch.randn((2, 360, 2), dtype=torch.float64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    sen, out = sensor.sense_plan_step(sv, st, goal, foot, noise)
+    torch.cuda.synchronize()
+    assert sen["overflow"].tolist() == [1, 0] and int(sen["n_inferred"][1]) == 1
+    assert out["status"].tolist() == [lipmpc.STATUS_SENSOR_OVERFLOW, lipmpc.STATUS_SOLVED]
+    assert bool(torch.isnan(out["U"][0]).all()) and bool(torch.isnan(out["X"][0]).all()) and bool(torch.isfinite(out["U"][1]).all())
+    st2, foot2 = st.clone(), foot.clone()
+    sv.advance(st2, foot2, out)
+    torch.cuda.synchronize()
+    assert torch.equal(st2[0], st[0]) and int(foot2[0]) == 1                 # not walked against obstacles it sensed but dropped
+    assert not torch.equal(st2[1], st[1]) and int(foot2[1]) == -1
+    # the two-call form: the flags travel with the rows
+    sen2 = sensor.sense(st, noise, c_eta=True, rings=False)
+    o2 = sv.plan_step_batch_c_eta(st, goal, foot, sen2["c_eta"], overflow=sen2["overflow"])
+    torch.cuda.synchronize()
+    assert o2["status"].tolist() == out["status"].tolist() and torch.equal(o2["U"][1], out["U"][1])
+    # without the flags the truncated list is solved as given (the caller's responsibility, documented)
+    o3 = sv.plan_step_batch_c_eta(st, goal, foot, sen2["c_eta"])
+    torch.cuda.synchronize()
+    assert int(o3["status"][0]) in (lipmpc.STATUS_SOLVED, lipmpc.STATUS_UNCERTIFIED)
+
+
+@pytest.mark.gpu
 def test_gpu_constraint_assembly_fused_into_the_scan(golden_dir):
     """lipmpc_lidar_c_eta_batch (scan -> clusters -> hulls -> closest point / normal in ONE launch, hulls in LDS) against
     (a) the oracle chain lidar oracle -> closest_point_and_normal on the reference's golden scans and (b), for 4096

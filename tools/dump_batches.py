@@ -29,6 +29,34 @@ def dump(tag, B, N, n_obs, hi, goal, seed, steps, n_fields=None, delta_mix=False
     print(tag, np.bincount(g["g_status"], minlength=5), "iters", g["g_iters"].mean())
 
 
+def dump_bench(tag):
+    """bench.py's headline batch (BASELINE configs[1]) exactly as bench.py builds it, with the answers of whichever
+    library is loaded (LIPMPC_LIB=variants/<build>.so for a historical one)."""
+    import importlib.util
+    from importlib import import_module
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    synth = import_module("humanoid-navigation-using-mpc-ldcbf_amd.synth")
+    dev = torch.device("cuda", 0)
+    inp = bench.make_inputs(lipmpc, synth, 4096, 8, 10, 0, 0, dev, 0)
+    P = lipmpc.LipMpcParams(N=8, n_obs_max=10, v_max=5)
+    out = lipmpc.BatchedLipMpc(P).plan_step_batch(inp["state"], inp["goal"], inp["foot"], inp["obs_xy"], inp["obs_nv"], inp["delta"],
+                                                  with_diag=True, with_c_eta=True)
+    torch.cuda.synchronize()
+    g = {"g_" + k: v.cpu().numpy() for k, v in out.items()}
+    np.savez_compressed(os.path.join(ROOT, "gpurun_out", tag + ".npz"), state=inp["state"].cpu().numpy(), foot=inp["foot"].cpu().numpy(),
+                        goal=inp["goal"].cpu().numpy(), delta=inp["delta"].cpu().numpy(), xy=inp["obs_xy"].cpu().numpy(),
+                        nv=inp["obs_nv"].cpu().numpy(), **g)
+    print(tag, np.bincount(g["g_status"], minlength=5), "iters", g["g_iters"].mean())
+
+
 if __name__ == "__main__":
-    dump("cfg4_batch", 4096, 16, 50, 15.5, (16.0, 16.0), 31, 20, n_fields=1024)
-    dump("cfg2_batch", 4096, 8, 10, 9.5, (10.0, 10.0), 1234, 30, delta_mix=True)
+    what = sys.argv[1:] or ["cfg4", "cfg2"]
+    if "cfg4" in what:
+        dump("cfg4_batch", 4096, 16, 50, 15.5, (16.0, 16.0), 31, 20, n_fields=1024)
+    if "cfg2" in what:
+        dump("cfg2_batch", 4096, 8, 10, 9.5, (10.0, 10.0), 1234, 30, delta_mix=True)
+    for w in what:
+        if w.startswith("bench"):                 # bench or bench:<tag>
+            dump_bench(w.split(":", 1)[1] if ":" in w else "bench_batch_r03")

@@ -1,6 +1,6 @@
 #!/bin/bash
+# Dev tool: tools/lidar_uniform.py per phase with the -DLIPMPC_LIDAR_PHASES variant loaded from its own path (LIPMPC_LIB)
+set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
-L=$R/humanoid-navigation-using-mpc-ldcbf_amd/liblipmpc.so
-cp $L /tmp/liblipmpc.keep && cp $R/variants/phases.so $L
-for s in 1 2 3 0; do LIPMPC_LIDAR_STOP=$s python3 $R/tools/lidar_uniform.py 2>&1 | grep -v amdgpu.ids; done
-cp /tmp/liblipmpc.keep $L
+test -f $R/variants/phases.so
+for s in 1 2 3 0; do LIPMPC_LIB=$R/variants/phases.so LIPMPC_LIDAR_STOP=$s python3 $R/tools/lidar_uniform.py 2>&1 | grep -v amdgpu.ids; done
