@@ -188,6 +188,8 @@ def main():
     ap.add_argument("--horizon", type=int, default=8)
     ap.add_argument("--obstacles", type=int, default=10)
     ap.add_argument("--finish-rounds", type=int, default=0, help="lipmpc_params.finish_rounds (0 = library default)")
+    ap.add_argument("--fields", type=int, default=0,
+                    help="distinct obstacle fields (0 = one per robot); fewer: fields are reused by several robots (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the compact extras (BASELINE configs 3 on one GPU, 4 and 5: a few seconds; never `value`)")
@@ -261,7 +263,7 @@ def main():
     walker = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5, flags=lipmpc.FLAG_INTERIOR), local_rank)
 
     # ---- synthetic inputs (seeded per rank), placed in HBM before the timed region -------------
-    inp = make_inputs(lipmpc, synth, B, N, n_obs, lo, rank, dev, local_rank)
+    inp = make_inputs(lipmpc, synth, B, N, n_obs, lo, rank, dev, local_rank, n_fields=args.fields or None, walk_steps=30 if N <= 8 else 20)
     state, foot, goal, obs_xy, obs_nv, delta, walker = (inp[k] for k in ("state", "foot", "goal", "obs_xy", "obs_nv", "delta", "walker"))
     out = solver.alloc_outputs(B)
     # On a schedule the order a launch runs in is the one the PREVIOUS launch left.  Replaying one batch would make that an

@@ -16,7 +16,7 @@ EXTRA="$@"
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py --no-cpu-baseline $EXTRA > $O/bench_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py --no-cpu-baseline --no-other-configs $EXTRA > $O/bench_stats.log 2>&1
 find /tmp/prof_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 python3 - "$O" <<'PY'
 import csv, glob, sys
@@ -32,9 +32,10 @@ PY
 rm -rf /tmp/prof_stats
 echo "counter,mean_per_launch_over_the_10_timed_launches" > $O/pmc.csv
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" \
-         "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64"; do
+         "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64" \
+         "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAIT_ANY" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_INSTS_VMEM_RD"; do
   rm -rf /tmp/prof_pmc
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/prof_pmc -- python3 $R/bench.py --no-cpu-baseline --steps 10 --warmup 2 $EXTRA > $O/bench_pmc.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/prof_pmc -- python3 $R/bench.py --no-cpu-baseline --no-other-configs --steps 10 --warmup 2 $EXTRA > $O/bench_pmc.log 2>&1
   python3 - "$O" <<'PY'
 import csv, glob, sys, collections
 O = sys.argv[1]
