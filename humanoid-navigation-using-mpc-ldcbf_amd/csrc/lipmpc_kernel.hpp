@@ -276,6 +276,18 @@ __device__ __forceinline__ double zero_unless(bool c, double x) {
 // compiler from moving accesses across the point -- a workgroup-scope fence, no s_barrier.  Unlike __syncthreads()
 // this is well defined inside the divergent regions it is used in (groups of a wave leave the solver loops
 // independently).
+// Dev instrumentation (tools/phase_cycles.py, -DLIPMPC_PHASE_TIMING variant only): shader-clock cycles per section of the step,
+// summed over a wave's lifetime, written to diag[pb * 16 + k] (the tool hands in a [B,16] buffer).  Sections: 0 iteration head
+// (statistics, streamed pass A), 1 reciprocals + K, 2 factorisation, 3 predictor rhs + solve, 4 predictor rows / ratio / mu_aff,
+// 5 corrector rhs + solve, 6 corrector rows / ratio / update, 7 finish: K + factorisation, 8 finish: equality solve,
+// 9 finish: ratio test / exchange / certificate, 10 front end, 11 outputs.
+#ifdef LIPMPC_PHASE_TIMING
+#define PH_DECL long long ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long ph_t = __builtin_readcyclecounter();
+#define PH(k) { const long long n_ = __builtin_readcyclecounter(); ph_acc[k] += n_ - ph_t; ph_t = n_; }
+#else
+#define PH_DECL
+#define PH(k)
+#endif
 constexpr int WAVE = 64;
 __device__ __forceinline__ void wave_sync() {
 #ifdef LIPMPC_SYNCTHREADS
@@ -407,9 +419,10 @@ __device__ __forceinline__ StepOut step_body(
   constexpr int MAXOBS = 2 * NOBS_L;
   constexpr int MAXWORDS = 16;         // (9*16 + 17*50 + 63)/64 = 16
 #ifdef LIPMPC_NO_FUSED_DPP
-  constexpr bool FUSED = false;
+  constexpr bool FUSED = false, FUSED32 = false;
 #else
   constexpr bool FUSED = (G == 16);    // one-instruction substitution / elimination steps (fmac_bcast)
+  constexpr bool FUSED32 = (G == 32);  // the same on two DPP rows per problem (FactorStep32, solve32_*: row-masked chains)
 #endif
 
   // a problem's obstacle rings staged in LDS by one coalesced sweep of the group when they fit (n_obs x v_max vertices
@@ -424,6 +437,7 @@ __device__ __forceinline__ StepOut step_body(
   __shared__ double lds_mu[GPW][2];      // no-progress safeguard: mu of the previous iteration, sigma floor of this one
   __shared__ double lds_sz[GPW][NOBS_S > 0 ? NOBS_S : 1][G][2];   // streamed rows: (s, z) then (s, y); lane-contiguous
 
+  PH_DECL
   const int tid = threadIdx.x;
   const int lane = tid & (G - 1);
   const int grp = tid / G;
@@ -663,14 +677,28 @@ __device__ __forceinline__ StepOut step_body(
   };
   // G = 16: the triangular factors in the form the fused substitution steps want them (solve):
   //   Xl[j] = -Lt[l][j] / p_j on lanes l > j, 0 elsewhere;  Yu[j] = -Lt[j][l] / p_l ... = -ipiv_l S_l[j] on lanes l < j, 0 elsewhere
-  double Xl[FUSED ? NV : 1], Yu[FUSED ? NV : 1];
+  double Xl[(FUSED || FUSED32) ? NV : 1], Yu[(FUSED || FUSED32) ? NV : 1];
   auto factor = [&]() -> bool {
     bool ok = true;
     const int ln = fresh(lane);
-    if constexpr (FUSED) dpp_fence();
+    if constexpr (FUSED || FUSED32) dpp_fence();
     static_for<0, NV>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      if constexpr (FUSED) {
+      if constexpr (FUSED32) {
+        // Two DPP rows per problem.  Row j of the Schur complement equals its column j, and the column is lane-distributed
+        // (lane cc holds S[cc][j] in Krow[j]): ONE cross-row exchange per step makes both 16-lane halves of the column
+        // visible in every row, after which each update S[l][cc] -= (S[l][j] / p_j) S[cc][j] is one v_fmac_f64_dpp with the
+        // broadcast of S[cc][j] as its DPP operand (LDL^T form; see the unfused branch below for why not Cholesky form)
+        double cA, cB;                                    // S[0..15][j], S[16..31][j] by local lane position
+        rowpair(Krow[j], cA, cB);
+        const double pj = bc16(std::integral_constant<int, (j & 15)>{}, j < 16 ? cA : cB);
+        ok = ok && (pj > 0.0);
+        const double ip = fast_rcp(pj);
+        ipiv = (ln == j) ? ip : ipiv;
+        const double ng = zero_unless(ln > j, Krow[j] * -ip);
+        Xl[j] = ng;
+        FactorStep32<j>::run(Krow, cA, cB, ng);
+      } else if constexpr (FUSED) {
         const double pj = gbcast<G, j>(Krow[j]);
         ok = ok && (pj > 0.0);
         const double ip = fast_rcp(pj);
@@ -708,7 +736,7 @@ __device__ __forceinline__ StepOut step_body(
         });
       }
     });
-    if constexpr (FUSED) {
+    if constexpr (FUSED || FUSED32) {
       const double nip = -ipiv;
       static_for<1, NV>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -725,6 +753,22 @@ __device__ __forceinline__ StepOut step_body(
       dpp_fence();
       b = solve_forward_chain(b, Xl);
       return solve_backward_chain(b * ipiv, Yu);
+    } else if constexpr (FUSED32) {
+      // The same recurrences on two DPP rows, the substitution chain inside one row at a time (row_mask): columns 0..15
+      // among the lanes of the low row, the high row catches up on those 16 columns after ONE cross-row exchange of the
+      // finished values, columns 16..31 inside the high row; and the mirror image backwards.  Xl / Yu hold the
+      // coefficients by group lane position (zero where a link does not apply), so a link is one v_fmac_f64_dpp.
+      dpp_fence();
+      b = solve32_fwd_lo(b, Xl);
+      double lo_rep, hi_rep;
+      rowpair(b, lo_rep, hi_rep);                         // lo_rep: the low row's b_0..b_15 by local lane position
+      b = solve32_fwd_x(b, lo_rep, Xl);
+      b = solve32_fwd_hi(b, Xl);
+      double x = b * ipiv;
+      x = solve32_bwd_hi(x, Yu);
+      rowpair(x, lo_rep, hi_rep);                         // hi_rep: x_16..x_31
+      x = solve32_bwd_x(x, hi_rep, Yu);
+      return solve32_bwd_lo(x, Yu);
     } else if constexpr (G == 16) {
       // forward Lt w = b: w_j = b_j / p_j, b_l -= Lt[l][j] w_j (l > j); lane j's b is final after step j
       static_for<0, NV>([&](auto jc) {
@@ -891,6 +935,7 @@ __device__ __forceinline__ StepOut step_body(
   // Groups of a wave leave the loop independently (real divergence: a finished group's lanes are
   // simply masked off; all exchanges inside are row-local DPP / group-local LDS).
   if (lane == 0) { lds_mu[grp][0] = INFINITY; lds_mu[grp][1] = 0.0; }
+  PH(10)
   for (int it = 0; it <= P.max_iter; ++it) {
     if (__all(done)) break;
     if (!done) {
@@ -935,6 +980,7 @@ __device__ __forceinline__ StepOut step_body(
       if (rpmax <= P.tol && mu <= P.tol) { status = LIPMPC_STATUS_SOLVED; done = true; iters = it; }
       else if (it == P.max_iter) { done = true; iters = it; }
       else if (bad) { status = LIPMPC_STATUS_INFEASIBLE; done = true; iters = it; }
+      PH(0)
       if (!done) {
         // Reciprocals once per row and iteration; every later division becomes a multiply, and the
         // ratio tests run on -ds/s, -dz/z (largest ratio r => step 1/r) so they need no division.
@@ -949,7 +995,9 @@ __device__ __forceinline__ StepOut step_body(
           d[i] = z[i] * is_[i];
         }
         K_rows(d, cxs, cxys, cys);
+        PH(1)
         const bool fok = factor();
+        PH(2)
         if (!fok) {
           // K loses numerical definiteness once max(z/s) ~ 1e15: near the solution that is
           // "converged to working precision" (the finish takes over), elsewhere infeasibility
@@ -962,6 +1010,7 @@ __device__ __forceinline__ StepOut step_body(
 #pragma unroll
         for (int i = 0; i < NR; ++i) w[i] = fma(d[i], rp[i] - s[i], z[i]);
         const double dqa = solve(m2qg - GT_rows(w, axs, ays));
+        PH(3)
         double dl[NR], c2[NR];                             // c2 = ds_aff dz_aff: all the corrector needs of the predictor
         rows_dir(dqa, dl);
         const double ax_ = cx_, ay_ = cy_;                  // predictor direction of this stage (streamed rows)
@@ -995,6 +1044,7 @@ __device__ __forceinline__ StepOut step_body(
         double sigma = ratio * ratio * ratio;
         sigma = fmax(sigma, lds_mu[grp][1]);      // no-progress safeguard: floor computed at the top of the iteration
         const double sigma_mu = sigma * mu;
+        PH(4)
         // corrector: rc = s z + ds_a dz_a - sigma mu
         double rc[NR];
 #pragma unroll
@@ -1015,6 +1065,7 @@ __device__ __forceinline__ StepOut step_body(
           }
         }
         const double dq = solve(m2qg - GT_rows(w, axs, ays));
+        PH(5)
         rows_dir(dq, dl);
         const double bx_ = cx_, by_ = cy_;                  // corrector direction of this stage
         r_l = IPM_STEP_FRAC;                               // alpha = min(1, 0.995 / max ratio)
@@ -1065,6 +1116,7 @@ __device__ __forceinline__ StepOut step_body(
             s[i] = fma(alpha, ds[i], s[i]); z[i] = fma(alpha, dz[i], z[i]); rp[i] *= oma;
           }
         }
+        PH(6)
       }
     }
   }
@@ -1149,7 +1201,7 @@ __device__ __forceinline__ StepOut step_body(
       s_obs(t, ex, ey, bb);
       const double sl = ex * fx + ey * fy - bb, gd = -(ex * ddx + ey * ddy);       // g = -eta
       const bool cand = gd > FIN_GD_MIN;
-      return cand ? fmax(sl + gd, 0.0) / (cand ? gd : 1.0) : INFINITY;
+      return cand ? fmax(sl + gd, 0.0) * fast_rcp(gd) : INFINITY;
     };
     for (int rnd = 0; rnd < P.fin_rounds; ++rnd) {
       if (__all(fin_done)) break;
@@ -1167,8 +1219,10 @@ __device__ __forceinline__ StepOut step_body(
           }
         }
       }
+      PH(9)
       K_rows(d, cxs, cxys, cys);
       const bool fok = factor();
+      PH(7)
       qf = xf;                                         // the equality solve starts at the current point
       double eres = INFINITY, rd_g = 0.0, r_g = 0.0;
       for (int in = 0; in <= FIN_INNER; ++in) {
@@ -1227,6 +1281,7 @@ __device__ __forceinline__ StepOut step_body(
           }
         }
       }
+      PH(8)
       // (slk holds the slack functions of the final qf: every pass of the loop above evaluates them before it decides to stop)
       // ratio test along d = qf - xf: slack at x = slack at qf + g.d; entry of a row outside A the direction runs into:
       // max(slack at x, 0) / g.d; the smallest entry below 1 blocks the step
@@ -1239,7 +1294,9 @@ __device__ __forceinline__ StepOut step_body(
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
         const bool cand = pres[i] & !act[i] & (gd[i] > FIN_GD_MIN);
-        rr[i] = cand ? fmax(slk[i] + gd[i], 0.0) / (cand ? gd[i] : 1.0) : INFINITY;
+        // (reciprocal to 2e-15 instead of the IEEE division of the oracles: 26 instead of 74 cycles per row on the round's
+        // serial path; the last bit of a ratio only matters on an exact tie between two blocking rows)
+        rr[i] = cand ? fmax(slk[i] + gd[i], 0.0) * fast_rcp(gd[i]) : INFINITY;
         rbest = fmin(rbest, rr[i]);
       }
       // multipliers on A and slack functions outside A at qf: the VALUES first (group extrema).  Most rounds end here,
@@ -1337,6 +1394,7 @@ __device__ __forceinline__ StepOut step_body(
     }
   }
 
+  PH(9)
   // ---- outputs -----------------------------------------------------------------------------------
   const bool have_sol = (status == LIPMPC_STATUS_SOLVED) || (status == LIPMPC_STATUS_UNCERTIFIED);
   // velocities v_{a+1} of the solution
@@ -1381,11 +1439,20 @@ __device__ __forceinline__ StepOut step_body(
       obj_out[pb] = have_sol ? objv : nanv;
       status_out[pb] = status;
       iters_out[pb] = iters;
+#ifndef LIPMPC_PHASE_TIMING
       if (diag) { diag[pb * 4 + 0] = diag_rounds; diag[pb * 4 + 1] = diag_eres; diag[pb * 4 + 2] = margin; diag[pb * 4 + 3] = diag_cert; }
+#endif
       if (cost_out) cost_out[pb] = iters + 2 * (int)diag_rounds;      // this problem's weight for the next launch's order (a finish round ~ 1.5-2 iterations)
     }
     for (int wi = lane; wi < P.words; wi += G) active_out[pb * P.words + wi] = lds_act[grp][wi];
   }
+  PH(11)
+#ifdef LIPMPC_PHASE_TIMING
+  if (valid && diag && lane == 0) {
+    for (int k = 0; k < 12; ++k) diag[pb * 16 + k] = (double)ph_acc[k];
+    diag[pb * 16 + 12] = iters; diag[pb * 16 + 13] = diag_rounds;
+  }
+#endif
   StepOut r;
   r.status = status; r.iters = iters; r.theta1 = theta1; r.omega0 = omega0; r.obj = objv;
   r.ux = gbcast<G, 0>(u); r.uy = gbcast<G, 1>(u);

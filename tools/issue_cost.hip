@@ -61,6 +61,21 @@ template <int MODE> __global__ __launch_bounds__(64) void k(double* out, long lo
         asm volatile("v_max_f64 %0, %0, %8\n\tv_max_f64 %1, %1, %8\n\tv_max_f64 %2, %2, %8\n\tv_max_f64 %3, %3, %8\n\t"
                      "v_max_f64 %4, %4, %8\n\tv_max_f64 %5, %5, %8\n\tv_max_f64 %6, %6, %8\n\tv_max_f64 %7, %7, %8"
                      : "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i2) : "v"(m));
+      } else if constexpr (MODE == 13) { // 8 independent v_rcp_f64
+        asm volatile("v_rcp_f64 %0, %0\n\tv_rcp_f64 %1, %1\n\tv_rcp_f64 %2, %2\n\tv_rcp_f64 %3, %3\n\t"
+                     "v_rcp_f64 %4, %4\n\tv_rcp_f64 %5, %5\n\tv_rcp_f64 %6, %6\n\tv_rcp_f64 %7, %7"
+                     : "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i2));
+      } else if constexpr (MODE == 14) { // dependent plain fma
+        b = fma(b, m, m);
+      } else if constexpr (MODE == 15) { // 8 independent v_permlane16_swap_b32
+        asm volatile("v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\tv_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\t"
+                     "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\tv_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7"
+                     : "+v"(((int*)&b)[0]), "+v"(((int*)&c)[0]), "+v"(((int*)&d)[0]), "+v"(((int*)&e)[0]), "+v"(((int*)&f)[0]), "+v"(((int*)&g)[0]), "+v"(((int*)&h)[0]), "+v"(((int*)&i2)[0]));
+      } else if constexpr (MODE == 16) { // dependent IEEE division
+        b = m / b + 1.0;
+      } else if constexpr (MODE == 17) { // 8 independent 64-bit selects (2 v_cndmask_b32 each)
+        b = (threadIdx.x & 1) ? b : c; c = (threadIdx.x & 2) ? c : d; d = (threadIdx.x & 4) ? d : e; e = (threadIdx.x & 8) ? e : f;
+        f = (threadIdx.x & 16) ? f : g; g = (threadIdx.x & 32) ? g : h; h = (threadIdx.x & 1) ? h : i2; i2 = (threadIdx.x & 2) ? i2 : b;
       } else if constexpr (MODE == 12) { // ds_read_b64 lane-private, 8 independent then wait
         __shared__ double sm[64 * 8];
         sm[threadIdx.x] = b;
@@ -91,5 +106,7 @@ int main() {
   R(6, "dep mov_b64_dpp + fma (per pair)", 1); R(7, "dep quad_perm pair + mul/add (per group)", 1);
   R(8, "indep v_mov_b32 x8", 8); R(9, "accvgpr write x4 + read x4 (per op)", 8); R(10, "dep rcp+add (per pair)", 1);
   R(11, "indep v_max_f64 x8", 8); R(12, "ds_read_b64 x8 + wait (per read)", 8);
+  R(13, "indep v_rcp_f64 x8", 8); R(14, "dep v_fma_f64", 1); R(15, "indep v_permlane16_swap_b32 x8", 8); R(16, "dep IEEE f64 division + add (per pair)", 1);
+  R(17, "64-bit selects x8 (per select)", 8);
   return 0;
 }
