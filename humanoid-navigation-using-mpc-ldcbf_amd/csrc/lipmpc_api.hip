@@ -144,6 +144,11 @@ int lipmpc_create(const lipmpc_params* p, int device, lipmpc_handle** out) {
   for (int i = 0; i < 2; ++i) { k.l_max[i] = p->l_max[i]; k.l_min[i] = p->l_min[i]; k.v_min[i] = p->v_min[i]; k.v_max[i] = p->v_max_xy[i]; }
   k.alpha_over_pi = p->alpha / M_PI; k.omega_max = p->omega_max; k.ell = p->ell; k.tau = p->sampling_time;
   k.tol = (p->flags & LIPMPC_FLAG_INTERIOR) ? p->tol_interior : p->tol; k.k0_tol = p->k0_tol;
+  {   // presolve bound (oracle: reach_step): the largest |p_{k+1} - p_k| the leg-reach rows allow
+#pragma clang fp contract(off)
+    const double dx = fmax(fabs(p->l_max[0]), fabs(p->l_min[0])), dy = fmax(fabs(p->l_max[1]), fabs(p->l_min[1])) + fabs(p->ell);
+    k.reach_step = sqrt(dx * dx + dy * dy);
+  }
   *out = h;
   return LIPMPC_OK;
 }

@@ -56,6 +56,7 @@ constexpr double FIN_IDENT = 1e5;   // initial working set z > FIN_IDENT * s: a 
 constexpr int FIN_INNER = 6;
 constexpr double FIN_INNER_TOL = 1e-11;
 constexpr double FIN_STALL = 0.5;      // a correction that leaves more than this share of the residual has stalled
+constexpr double SCREEN_MARGIN = 1e-3;   // presolve: an LDCBF row is dropped when the leg-reach rows keep it this far from active
 constexpr double WARM_Z_MIN = 3.0, WARM_Z_MAX = 100.0;   // closed-loop warm start: band of the shifted previous multipliers
 constexpr int WARM_ROWS = 12;                            // register row slots a lane can hold (5 kinematic + 7 LDCBF)
 
@@ -68,6 +69,7 @@ struct KArgs {
   double kappa, ch, sh_over_beta, inv_one_minus_ch, beta_sh;
   double l_max[2], l_min[2], v_min[2], v_max[2];
   double alpha_over_pi, omega_max, ell, tau, tol, k0_tol;
+  double reach_step;      // largest CoM displacement per stage the leg-reach rows allow (presolve of the LDCBF rows)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -489,6 +491,13 @@ __device__ __forceinline__ StepOut step_body(
   const double kap_l = on * kap;
 
   // ---- obstacles: c_j, eta_j at the current CoM (HumanoidMpc.py:296-319) ----------------------
+  // Presolve (oracle: presolve_ldcbf): every feasible p_k lies within k * reach_step of p_0, so the LDCBF row of obstacle j
+  // at stage k is REDUNDANT -- never active, never violated -- where its value at p_0 exceeds |eta_j| k reach_step by a
+  // margin; such rows leave the problem (kfirst_j = the first stage that keeps its row) and n_d copies of one ballast row
+  // 0.q <= s_bar (their mean slack) keep their averaging effect on mu / sigma in the interior-point phase.  Exact mode, cold
+  // start only: the answer there is the path-independent certified optimum.
+  const bool presolve = !(P.flags & (LIPMPC_FLAG_INTERIOR | LIPMPC_FLAG_NO_PRESOLVE)) && (warm == nullptr || warm->lds == nullptr);
+  double nd_l = 0.0, ss_l = 0.0;          // this lane's share of n_d and of the dropped rows' slack sum
   if (lane == 0) lds_flag[grp] = 0;
   const bool staged = MAXOBS > 0 && !c_eta_in && P.n_obs * P.nvert_max <= RING_CAP;     // wave-uniform
   if (staged) {
@@ -499,7 +508,7 @@ __device__ __forceinline__ StepOut step_body(
   wave_sync();
   if (MAXOBS > 0) {
     for (int j = lane; j < MAXOBS; j += G) {
-      if (j >= P.n_obs) {      // unused slot: absent (h0 = +inf), harmless values
+      if (j >= P.n_obs) {      // unused slot: absent (kfirst = +inf), harmless values
         lds_obs[grp][j][0] = 0.0; lds_obs[grp][j][1] = 0.0; lds_obs[grp][j][2] = 0.0; lds_obs[grp][j][3] = INFINITY;
         continue;
       }
@@ -521,14 +530,24 @@ __device__ __forceinline__ StepOut step_body(
           degen = cp.degenerate != 0;
         }
       }
+      double kfirst = INFINITY;                  // first stage whose row of this obstacle stays in the problem (+inf: empty slot)
       if (there) {
+#pragma clang fp contract(off)                   // (the same roundings as the oracles: the screening test below compares them)
         const double ec = ex * cx + ey * cy;
         bb = ec + delta;
         h0 = (ex * p0x + ey * p0y) - ec - delta;
         if (degen) atomicOr(&lds_flag[grp], 2);
         else if (h0 < -P.k0_tol) atomicOr(&lds_flag[grp], 1);
-      }                                          // nv == 0: empty slot, h0 stays +inf
-      lds_obs[grp][j][0] = ex; lds_obs[grp][j][1] = ey; lds_obs[grp][j][2] = bb; lds_obs[grp][j][3] = h0;
+        int kf = 1;
+        if (presolve) {
+          const double es = sqrt(ex * ex + ey * ey) * P.reach_step;
+          while (kf <= N && h0 > es * (double)kf + SCREEN_MARGIN) ++kf;
+          nd_l += (double)(kf - 1);
+          ss_l += (double)(kf - 1) * h0;
+        }
+        kfirst = (double)kf;
+      }                                          // nv == 0: empty slot
+      lds_obs[grp][j][0] = ex; lds_obs[grp][j][1] = ey; lds_obs[grp][j][2] = bb; lds_obs[grp][j][3] = kfirst;
       if (c_eta && valid) {
         double* o = c_eta + oidx * 4;
         o[0] = cx; o[1] = cy; o[2] = ex; o[3] = ey;
@@ -537,6 +556,12 @@ __device__ __forceinline__ StepOut step_body(
   }
   wave_sync();
   const int front_flag = lds_flag[grp];
+  // the ballast row: n_d copies of 0.q <= s_bar, hosted in the manoeuvrability slot of lane 1 (a = 0, c = 1: that slot holds no
+  // row there and its direction coefficient cm is zero), weighted n_d in the two sums it enters
+  const double n_ball = MAXOBS > 0 ? gsum<G>(nd_l) : 0.0;
+  const double s_ball = n_ball > 0.0 ? gsum<G>(ss_l) / n_ball : 0.0;
+  const bool ball = (lane == 1) && (n_ball > 0.0);
+  const double ball_w = ball ? n_ball - 1.0 : 0.0;       // the slot counts once by itself
 
   // per-lane LDCBF rows: obstacle j = 2t + c, h = oo * p_own + oq * p_partner - ob (eta in own / partner order);
   // an absent slot is the constant row 0 . p - (-1) = 1
@@ -545,7 +570,7 @@ __device__ __forceinline__ StepOut step_body(
 #pragma unroll
   for (int t = 0; t < NOBS_R; ++t) {
     const int j = 2 * t + c;
-    const bool there = var_on && (lds_obs[grp][j][3] != INFINITY);
+    const bool there = var_on && ((double)(a + 1) >= lds_obs[grp][j][3]);
     const double ex = lds_obs[grp][j][0], ey = lds_obs[grp][j][1];
     oo[t] = there ? (c ? ey : ex) : 0.0; oq[t] = there ? (c ? ex : ey) : 0.0;
     ob[t] = there ? lds_obs[grp][j][2] : -1.0;
@@ -555,14 +580,14 @@ __device__ __forceinline__ StepOut step_body(
   unsigned pbits = 0u;
 #pragma unroll
   for (int t = 0; t < NOBS_S; ++t)
-    if (var_on && lds_obs[grp][2 * t + c][3] != INFINITY) pbits |= 1u << t;
+    if (var_on && (double)(a + 1) >= lds_obs[grp][2 * t + c][3]) pbits |= 1u << t;
   auto s_obs = [&](int t, double& ex, double& ey, double& b) {
     const double* o = lds_obs[grp][2 * t + c];
     ex = o[0]; ey = o[1]; b = o[2];
   };
   auto s_pm = [&](int t) -> double { return ((pbits >> t) & 1u) ? 1.0 : 0.0; };
   pres.set(R_RU, var_on); pres.set(R_RL, var_on); pres.set(R_VU, var_on); pres.set(R_VL, var_on);
-  pres.set(R_M, var_on && (c == 0));
+  pres.set(R_M, (var_on && (c == 0)) || ball);
 
   // bounds of the non-LDCBF rows
   const double hi_r = P.l_max[c], lo_r = P.l_min[c];
@@ -577,7 +602,7 @@ __device__ __forceinline__ StepOut step_body(
   int n_rows_l = __popc(pbits);
 #pragma unroll
   for (int i = 0; i < NR; ++i) n_rows_l += pres[i] ? 1 : 0;
-  const double m_rows = gsum<G>((double)n_rows_l);
+  const double m_rows = gsum<G>((double)n_rows_l) + fmax(n_ball - 1.0, 0.0);
   const double inv_m = 1.0 / fmax(m_rows, 1.0);
 
   // ---- linear row maps -------------------------------------------------------------------------
@@ -869,16 +894,17 @@ __device__ __forceinline__ StepOut step_body(
     double wc[NOBS_R > 0 ? NOBS_R : 1];
 #pragma unroll
     for (int t = 0; t < NOBS_R; ++t) wc[t] = w[R_CBF + t];
-    return GT_apply(w[R_RU] - w[R_RL], w[R_VU] - w[R_VL] + w[R_M], wc, axs, ays);
+    return GT_apply(w[R_RU] - w[R_RL], fma(cm, w[R_M], w[R_VU] - w[R_VL]), wc, axs, ays);      // (cm: not the ballast row's slot)
   };
   auto K_rows = [&](const double (&d)[NR], double cxs, double cxys, double cys) {
     double dc[NOBS_R > 0 ? NOBS_R : 1];
 #pragma unroll
     for (int t = 0; t < NOBS_R; ++t) dc[t] = d[R_CBF + t];
-    form_K(d[R_RU] + d[R_RL], d[R_VU] + d[R_VL] + d[R_M], dc, cxs, cxys, cys);
+    form_K(d[R_RU] + d[R_RL], fma(cm, d[R_M], d[R_VU] + d[R_VL]), dc, cxs, cxys, cys);
   };
 
   slack_values(q);
+  slk[R_M] = ball ? s_ball : slk[R_M];
   // An absent row (empty obstacle slot, manoeuvrability on the c = 1 lane, lane without a variable) is the constant
   // row 0 . q <= 1 with s = slk = 1, z = 0: its direction coefficients are zero, so r_p, ds, dz and its weights stay
   // exactly zero through the iteration with ONE masked quantity, 1/s (below), instead of a mask on every product.
@@ -947,6 +973,7 @@ __device__ __forceinline__ StepOut step_body(
         rpmax_l = fmax(rpmax_l, fabs(rp[i]));
         zmax_l = fmax(zmax_l, z[i]);
       }
+      mu_l = fma(ball_w * s[R_M], z[R_M], mu_l);           // the other n_d - 1 copies of the ballast row
       // streamed rows, pass A: residual statistics, K blocks and predictor weights in one sweep
       double qx = 0.0, qy = 0.0, cxs = 0.0, cxys = 0.0, cys = 0.0, axs = 0.0, ays = 0.0;
       if constexpr (STREAM) {
@@ -1026,6 +1053,7 @@ __device__ __forceinline__ StepOut step_body(
           c2[i] = dsa * dza;
           s2_l += c2[i];
         }
+        s2_l = fma(ball_w, c2[R_M], s2_l);
         if constexpr (STREAM) {                            // pass B
 #pragma unroll STREAM_UNROLL
           for (int t = 0; t < NOBS_S; ++t) {
@@ -1121,6 +1149,7 @@ __device__ __forceinline__ StepOut step_body(
     }
   }
 
+  if (ball) { pres.set(R_M, false); s[R_M] = 1.0; z[R_M] = 0.0; }      // the ballast row ends with the interior-point phase
   if (warm_on) {                              // park this step's interior-point result for the next step
     wave_sync();                              // (every lane has read its neighbours' previous values by now)
     warm->lds[lane] = q;

@@ -15,6 +15,7 @@ STATUS_SOLVED, STATUS_MAX_ITER, STATUS_INFEASIBLE, STATUS_DEGENERATE, STATUS_UNC
 STATUS_SENSOR_OVERFLOW = 5     # a scan's clusters did not fit the obstacle slots: not solved (sense_plan_step, plan_step_batch_c_eta(overflow=)), robot stopped (fleet loop)
 FLAG_INTERIOR = 1
 FLAG_WARM_START = 2      # rollout: start every step from the previous step's shifted interior-point result
+FLAG_NO_PRESOLVE = 4     # keep the LDCBF rows the leg-reach rows make redundant in the solve (include/lipmpc.h)
 
 
 @dataclass

@@ -53,6 +53,13 @@ extern "C" {
                                    instead of "stand still", z = 30 -- the reference seeds its next solve with the shifted
                                    prediction, HumanoidMpc.py:450-455.  Same optimum, fewer iterations (-15..-30 %).
                                    Ignored for more than 14 obstacle slots and for N = 1. */
+#define LIPMPC_FLAG_NO_PRESOLVE 4 /* keep every LDCBF row in the solve.  By default (exact mode, cold start) the rows that the
+                                   leg-reach rows make redundant -- obstacle j at stage k with eta_j.(p_0 - c_j) - delta >
+                                   k * (largest CoM step the reach rows allow) + 1e-3: never active, never violated -- are
+                                   dropped before the solve and replaced, in the interior-point phase only, by copies of one
+                                   direction-free ballast row (oracle/lipmpc_oracle.py: presolve_ldcbf).  Same feasible set,
+                                   same minimiser, same active set; only the interior iterates differ, which is why
+                                   LIPMPC_FLAG_INTERIOR and LIPMPC_FLAG_WARM_START imply this flag. */
 
 /* error codes */
 #define LIPMPC_OK            0

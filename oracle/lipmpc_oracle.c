@@ -39,6 +39,7 @@ static const int IPM_SLOW_FROM = 8;
 static const double IPM_SLOW_RATIO = 0.9, IPM_SLOW_SIGMA = 0.5;   /* no-progress safeguard, see lipmpc_oracle.py */
 static const double FIN_RHO = 1e10, FIN_EPS = 1e-9, FIN_INNER_TOL = 1e-11, FIN_IDENT = 1e5, FIN_STALL = 0.5;
 static const double FIN_GD_MIN = 1e-14, FIN_DUAL_REL = 1e-14, FIN_RHO_POLISH = 1e12, FIN_POLISH_TOL = 1e-10;
+static const double SCREEN_MARGIN = 1e-3;     /* presolve: see lipmpc_oracle.py */
 enum { FIN_ROUNDS = 8, FIN_ROUNDS_LONG = 16, FIN_INNER = 6 };
 
 /* ---- geometry (ObstaclesUtils.py:50-109) ------------------------------------------------ */
@@ -188,7 +189,7 @@ static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, cons
   double sv[17];
   for (int i = 0; i <= N; ++i) sv[i] = (i % 2 == 0) ? (double)foot0 : -(double)foot0;
   /* c, eta per obstacle (HumanoidMpc.py:296-319) */
-  double ex[50], ey[50], bb[50];
+  double ex[50], ey[50], bb[50], h0v[50];
   int present[50];
   int flag = 0;
   for (int j = 0; j < n_obs; ++j) {
@@ -207,6 +208,7 @@ static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, cons
       double ec = ex[j] * cx + ey[j] * cy;
       bb[j] = ec + delta;
       double h0 = (ex[j] * p0[0] + ey[j] * p0[1]) - ec - delta;
+      h0v[j] = h0;
       if (dg) flag |= 2; else if (h0 < -P->k0_tol) flag |= 1;
     }
     if (c_eta) { c_eta[4 * j] = cx; c_eta[4 * j + 1] = cy; c_eta[4 * j + 2] = ex[j]; c_eta[4 * j + 3] = ey[j]; }
@@ -273,15 +275,37 @@ static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, cons
         ++m;
       }
   }
+  /* presolve (lipmpc_oracle.py: presolve_ldcbf): the LDCBF rows the leg-reach rows make redundant leave the problem; n_d
+   * copies of one ballast row 0.q <= s_bar keep their averaging effect on the interior-point iteration */
+  const int presolve = !(P->flags & (LIPMPC_FLAG_INTERIOR | LIPMPC_FLAG_WARM_START | LIPMPC_FLAG_NO_PRESOLVE));
+  double es[50];
+  int n_ballast = 0;
+  double s_ballast = 0.0;
+  if (presolve) {
+    const double dx = fmax(fabs(P->l_max[0]), fabs(P->l_min[0])), dy = fmax(fabs(P->l_max[1]), fabs(P->l_min[1])) + fabs(P->ell);
+    const double step = sqrt(dx * dx + dy * dy);
+    for (int j = 0; j < n_obs; ++j) {
+      if (!present[j]) continue;
+      es[j] = sqrt(ex[j] * ex[j] + ey[j] * ey[j]) * step;
+      int nd_j = 0;
+      for (int k = 1; k <= N; ++k) if (h0v[j] > es[j] * k + SCREEN_MARGIN) ++nd_j;
+      n_ballast += nd_j;
+      s_ballast += nd_j * h0v[j];
+    }
+    if (n_ballast) s_ballast /= n_ballast;
+  }
   for (int k = 1; k <= N; ++k)            /* LDCBF k = 1..N: -eta.p_k <= -(delta + eta.c) */
     for (int j = 0; j < n_obs; ++j) {
       if (!present[j]) continue;
+      if (presolve && h0v[j] > es[j] * k + SCREEN_MARGIN) continue;
       NEWROW(9 * N + k * n_obs + j);
       G[(size_t)m * n + 2 * (k - 1)] = -ex[j];
       G[(size_t)m * n + 2 * (k - 1) + 1] = -ey[j];
       h[m] = -bb[j];
       ++m;
     }
+  const int m_real = m;
+  for (int i = 0; i < n_ballast; ++i) { NEWROW(-1); h[m] = s_ballast; ++m; }     /* ballast rows: interior-point phase only */
 #undef NEWROW
   double g[NMAXV], q[NMAXV], rd[NMAXV], dq[NMAXV], tmp[NMAXV];
   for (int k = 0; k < N; ++k) { g[2 * k] = goal[0]; g[2 * k + 1] = goal[1]; q[2 * k] = p0[0]; q[2 * k + 1] = p0[1]; }
@@ -348,6 +372,7 @@ static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, cons
   *iters_out = it;
   *status_out = status;
   if (status != LIPMPC_STATUS_SOLVED) return;
+  m = m_real;                               /* the finish and the outputs see the real rows only */
   double margin = INFINITY;
   for (int i = 0; i < m; ++i) margin = fmin(margin, fabs(log(z[i] / (FIN_IDENT * s[i]))));
   if (diag) { diag[2] = margin; diag[3] = 0.0; }

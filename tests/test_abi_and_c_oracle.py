@@ -100,20 +100,57 @@ def test_c_oracle_equals_numpy_oracle(N, n_obs):
         assert np.array_equal(act[b], r["active"])
 
 
+def test_presolve_keeps_the_optimum_and_both_oracles_agree():
+    """The presolve (rows the leg-reach rows make redundant leave the problem, a ballast row keeps their averaging effect on
+    the interior-point iteration: oracle presolve_ldcbf) changes the path, not the answer: same statuses, same footsteps to
+    1e-7, same active sets wherever the certificate is decisive, with and without it; numpy and C oracle agree on both."""
+    from helpers import CERT_MARGIN
+    N, n_obs = 8, 10
+    probs = list(closed_loop_problems(N, n_obs, 4, 12, seed=5))
+    xy, nv = lipmpc.pack_rings([p[3] for p in probs], n_obs, 5)
+    args = (np.array([p[0] for p in probs]), np.array([p[1] for p in probs], float), np.array([p[2] for p in probs], np.int8), xy, nv,
+            np.array([p[4] for p in probs], float))
+    on = c_oracle.plan_step_batch(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5), *args, n_threads=2)
+    off = c_oracle.plan_step_batch(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5, flags=lipmpc.FLAG_NO_PRESOLVE), *args, n_threads=2)
+    assert np.array_equal(on["status"], off["status"])
+    ok = on["status"] == 0
+    assert ok.sum() >= 0.9 * len(probs) and np.max(np.abs(on["U"][ok] - off["U"][ok])) < 1e-7
+    firm = ok & (on["diag"][:, 3] >= CERT_MARGIN) & (off["diag"][:, 3] >= CERT_MARGIN)
+    assert firm.sum() >= 0.8 * ok.sum() and np.array_equal(on["active"][firm], off["active"][firm])
+    dropped = 0
+    for b, (st, goal, s0, obs, delta) in enumerate(probs):
+        x0 = np.asarray(st[:4], float)
+        cs, etas, _ = O.list_c_and_eta(x0, obs)
+        red, n_d, s_bar = O.presolve_ldcbf(x0, cs, etas, delta, O.Params(N=N))
+        dropped += n_d
+        assert n_d == red.sum() and (n_d == 0 or s_bar > O.reach_step(O.Params(N=N)))
+        for pre in (True, False):
+            r = O.plan_step(st, goal, s0, obs, delta, O.Params(N=N, presolve=pre))
+            ref = on if pre else off
+            assert r["status"] == ref["status"][b] and r["iters"] == ref["iters"][b]
+            if r["status"] == 0:
+                assert np.max(np.abs(r["U"] - ref["U"][b])) < 1e-8
+                # a dropped row is never in the active set
+                act = np.asarray(r["active"])[9 * N + n_obs:].reshape(N, n_obs)
+                assert not np.any(act & red) if pre else True
+    assert dropped > 0.5 * N * n_obs * len(probs)          # most LDCBF rows of these fields are redundant
+
+
 @pytest.mark.parametrize("cap", [1, 2])
 def test_finish_rounds_cap_c_oracle_equals_numpy_oracle(cap):
     """lipmpc_params.finish_rounds reaches both oracles the same way (statuses, rounds and answers agree under a
     tight cap, where part of the batch ends UNCERTIFIED with the interior-point answer)."""
     N, n_obs = 8, 10
     probs = list(closed_loop_problems(N, n_obs, 3, 12, seed=77))
-    P = lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5, finish_rounds=cap)
+    # (every LDCBF row kept: with the presolve on, this small batch certifies in one round throughout)
+    P = lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5, finish_rounds=cap, flags=lipmpc.FLAG_NO_PRESOLVE)
     xy, nv = lipmpc.pack_rings([p[3] for p in probs], n_obs, 5)
     out = c_oracle.plan_step_batch(P, np.array([p[0] for p in probs]), np.array([p[1] for p in probs], float),
                                    np.array([p[2] for p in probs], np.int8), xy, nv,
                                    np.array([p[4] for p in probs], float), n_threads=2)
     n4 = 0
     for b, (st, goal, s0, obs, delta) in enumerate(probs):
-        r = O.plan_step(st, goal, s0, obs, delta, O.Params(N=N, finish_rounds=cap))
+        r = O.plan_step(st, goal, s0, obs, delta, O.Params(N=N, finish_rounds=cap, presolve=False))
         assert r["status"] == out["status"][b]
         if r["status"] in (O.STATUS_SOLVED, O.STATUS_UNCERTIFIED):
             assert r["rounds"] <= cap and out["diag"][b, 0] == r["rounds"]
