@@ -213,7 +213,16 @@ class HumanoidMPC:
                 break
             st = X_pred[:, k].copy()
             step_number = math.floor(k / self.mpc_step)
-            r = self._plan(st, self.s_v[step_number])
+            if is_mpc:
+                r = self._plan(st, self.s_v[step_number])
+            else:
+                # The reference assembles the LDCBF constraints on EVERY sample (HumanoidMpc.py:387: a subclass's
+                # _get_list_c_and_eta runs, its scan lists grow) but solves only on MPC samples (:415-417); the other samples
+                # advance the heading with the theta / omega recurrence alone (:137-160, 443-447)
+                if self._hooks_overridden():
+                    self._get_list_c_and_eta(float(st[0]), float(st[2]))
+                th, om = self._theta_omega(st)
+                r = {"theta": th, "omega": om}
             self.precomputed_theta, self.precomputed_omega = r["theta"], r["omega"]
             if is_mpc:
                 self.last_status = int(r["status"])
@@ -235,6 +244,18 @@ class HumanoidMPC:
                 X_pred[:4, k + 1] = st[:4]
             X_pred[4, k + 1] = r["theta"][1]
         return X_pred[:, :k + 1], U_pred[:, :k], initial_animator      # :457-459, 494
+
+    def _theta_omega(self, state5):
+        """HumanoidMpc.py:137-160 on the host (samples between two MPC steps): omega_k = clip(atan2(goal - p_0) - theta_k,
+        -OMEGA_MAX, OMEGA_MAX), theta_{k+1} = theta_k + omega_k * sampling_time -- the recurrence the kernel's front end runs."""
+        om_max = 0.156 * math.pi                                    # HumanoidMpc.py:21-22
+        psi = math.atan2(float(self.goal[1]) - float(state5[2]), float(self.goal[0]) - float(state5[0]))
+        th, om = [float(state5[4])], []
+        for _ in range(self.N_horizon):
+            w = min(max(psi - th[-1], -om_max), om_max)
+            om.append(w)
+            th.append(th[-1] + w * self.sampling_time)
+        return np.array(th), np.array(om)
 
     @staticmethod
     def _lip():

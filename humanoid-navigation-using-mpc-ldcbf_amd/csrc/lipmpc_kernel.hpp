@@ -394,15 +394,156 @@ __device__ __forceinline__ void load_bounds(const KArgs& P, const double* __rest
   }
 }
 
-// The whole MPC step of one problem on one group of G lanes.  Output pointers may be null.
-template <int G, int NOBS_L, int NVAR = G>
-__device__ __forceinline__ StepOut step_body(
+// What the front end of a step hands to its solve: headings of the lane's stage, the obstacles' half-spaces COMPACTED in
+// LDS (obs[slot] = eta_x, eta_y, b = eta.c + delta, kfirst = first stage whose row of this obstacle is in the problem;
+// perm[slot] = the obstacle's index in the caller's list, for the canonical row numbers), and the ballast row of the presolve.
+template <int G> struct FrontOut {
+  double th_r, th_v, om_a, theta1, omega0, s_own, c_own;   // theta_a, theta_{a+1}, omega_a of the lane's stage; theta_1, omega_0; sin / cos of the lane's angle
+  double n_ball, s_ball;                                    // presolve: number of dropped rows, their mean slack at p_0
+  int front_flag;                                           // 1: a constant k = 0 row is violated, 2: degenerate geometry
+  int n_rel;                                                // obstacle slots in use (group-uniform)
+};
+
+// Front end of a step (shared by every solver body of a kernel): theta / omega, closest point and normal per obstacle,
+// presolve, compaction of the obstacles that still have a row into the leading slots.
+template <int G, int MAXOBS>
+__device__ __forceinline__ FrontOut<G> front_end(
     const KArgs& P, const StepIn& in, const double* __restrict__ obs_xy, const int32_t* __restrict__ obs_nv,
-    double* __restrict__ U, double* __restrict__ X, double* __restrict__ theta_out,
-    double* __restrict__ omega_out, double* __restrict__ obj_out, int32_t* __restrict__ status_out,
-    int32_t* __restrict__ iters_out, unsigned long long* __restrict__ active_out, double* __restrict__ c_eta,
-    double* __restrict__ diag, const double* __restrict__ c_eta_in = nullptr, WarmIO* __restrict__ warm = nullptr,
-    int32_t* __restrict__ cost_out = nullptr) {
+    double* __restrict__ theta_out, double* __restrict__ omega_out, double* __restrict__ c_eta,
+    const double* __restrict__ c_eta_in, bool cold, double (*lds_ring)[2], double (*lds_obs)[4], int* lds_perm, int* lds_flag_g) {
+  constexpr int RING_CAP = (G == 16) ? 64 : 256;
+  FrontOut<G> F;
+  const int tid = threadIdx.x;
+  const int lane = tid & (G - 1);
+  const int grp = tid / G;
+  const bool valid = in.valid;
+  const long pb = in.pb;
+  const int N = P.N;
+  const int a = lane >> 1;             // stage index: variable = p_{a+1}
+  const int c = lane & 1;              // coordinate
+  const double p0x = in.p0x, p0y = in.p0y, th0 = in.th0;
+  const double gx = in.gx, gy = in.gy, delta = in.delta;
+
+  // ---- theta / omega (HumanoidMpc.py:137-160) -------------------------------------------------
+  const double psi = atan2(gy - p0y, gx - p0x);
+  double th_r = 0.0, th_v = 0.0, om_a = 0.0, theta1 = th0, omega0 = 0.0;
+  {
+    double th = th0;
+    if (valid && lane == 0 && theta_out) theta_out[pb * (N + 1)] = th0;
+    for (int k = 0; k < N; ++k) {
+      double w = fmin(fmax(psi - th, -in.omega_max), in.omega_max);
+      double thn = th + w * P.tau;
+      if (k == a) { th_r = th; th_v = thn; om_a = w; }
+      if (k == 0) { theta1 = thn; omega0 = w; }
+      if (valid && lane == 0 && theta_out) { omega_out[pb * N + k] = w; theta_out[pb * (N + 1) + k + 1] = thn; }
+      th = thn;
+    }
+  }
+  F.th_r = th_r; F.th_v = th_v; F.om_a = om_a; F.theta1 = theta1; F.omega0 = omega0;
+  // R(theta_a) and W(theta_{a+1}): one sincos per lane (the c = 0 lane of a stage takes theta_a, its partner
+  // theta_{a+1}), exchanged inside the stage by the solve
+  sincos(c ? th_v : th_r, &F.s_own, &F.c_own);
+
+  // ---- obstacles: c_j, eta_j at the current CoM (HumanoidMpc.py:296-319) ----------------------
+  // Presolve (oracle: presolve_ldcbf): every feasible p_k lies within k * reach_step of p_0, so the LDCBF row of obstacle j
+  // at stage k is REDUNDANT -- never active, never violated -- where its value at p_0 exceeds |eta_j| k reach_step by a
+  // margin; such rows leave the problem (kfirst_j = the first stage that keeps its row) and n_d copies of one ballast row
+  // 0.q <= s_bar (their mean slack) keep their averaging effect on mu / sigma in the interior-point phase.  Exact mode, cold
+  // start only: the answer there is the path-independent certified optimum.
+  // Compaction (cold start only: a warm start parks per-slot state between steps): the obstacles that still have a row move
+  // to the leading slots, so that the wave can run the smallest solver body that holds them (step_body).
+  const bool presolve = !(P.flags & (LIPMPC_FLAG_INTERIOR | LIPMPC_FLAG_NO_PRESOLVE)) && cold;
+  const bool compact = cold;
+  double nd_l = 0.0, ss_l = 0.0;          // this lane's share of n_d and of the dropped rows' slack sum
+  if (lane == 0) *lds_flag_g = 0;
+  const bool staged = MAXOBS > 0 && !c_eta_in && P.n_obs * P.nvert_max <= RING_CAP;     // wave-uniform
+  if (staged) {
+    const double* src = obs_xy + pb * (long)P.n_obs * P.nvert_max * 2;
+    double* dst = &lds_ring[0][0];
+    for (int v = lane; v < P.n_obs * P.nvert_max * 2; v += G) dst[v] = src[v];
+  }
+  if (MAXOBS > 0) {
+    for (int j = lane; j < MAXOBS; j += G) {       // every slot starts empty (kfirst = +inf), harmless values
+      lds_obs[j][0] = 0.0; lds_obs[j][1] = 0.0; lds_obs[j][2] = 0.0; lds_obs[j][3] = INFINITY;
+      lds_perm[j] = j;
+    }
+  }
+  wave_sync();
+  int n_rel = 0;
+  if (MAXOBS > 0) {
+    for (int j0 = 0; j0 < MAXOBS; j0 += G) {       // (uniform trip count: the compaction is a ballot over the wave)
+      const int j = j0 + lane;
+      bool keep = false;                           // this obstacle takes a slot
+      double cx = 0, cy = 0, ex = 0, ey = 0, bb = 0, h0 = INFINITY, kfirst = INFINITY;
+      if (j < P.n_obs) {
+        const long oidx = pb * P.n_obs + j;
+        bool there, degen = false;
+        if (c_eta_in) {      // caller-supplied half-spaces (the reference's _get_list_c_and_eta hook): eta = (0,0) = empty slot, NaN = degenerate
+          const double* ce = c_eta_in + oidx * 4;
+          cx = ce[0]; cy = ce[1]; ex = ce[2]; ey = ce[3];
+          there = (ex != 0.0) || (ey != 0.0);
+          degen = (ex != ex) || (ey != ey);       // NaN normal: the producer met degenerate geometry (lipmpc_lidar_c_eta_batch)
+        } else {
+          const int nv = obs_nv[oidx];
+          there = nv > 0;
+          if (there) {
+            const ClosestPoint cp = staged ? closest_point_impl(&lds_ring[j * P.nvert_max][0], nv, p0x, p0y)
+                                           : closest_point_normal(obs_xy + oidx * P.nvert_max * 2, nv, p0x, p0y);
+            cx = cp.cx; cy = cp.cy; ex = cp.ex; ey = cp.ey;
+            degen = cp.degenerate != 0;
+          }
+        }
+        if (there) {
+#pragma clang fp contract(off)                   // (the same roundings as the oracles: the screening test below compares them)
+          const double ec = ex * cx + ey * cy;
+          bb = ec + delta;
+          h0 = (ex * p0x + ey * p0y) - ec - delta;
+          if (degen) atomicOr(lds_flag_g, 2);
+          else if (h0 < -P.k0_tol) atomicOr(lds_flag_g, 1);
+          int kf = 1;
+          if (presolve) {
+            const double es = sqrt(ex * ex + ey * ey) * P.reach_step;
+            while (kf <= N && h0 > es * (double)kf + SCREEN_MARGIN) ++kf;
+            nd_l += (double)(kf - 1);
+            ss_l += (double)(kf - 1) * h0;
+          }
+          kfirst = (double)kf;
+          keep = kf <= N;                          // (every stage dropped: the obstacle is in the ballast only)
+        }                                          // nv == 0: empty slot
+        if (c_eta && valid) {
+          double* o = c_eta + oidx * 4;
+          o[0] = cx; o[1] = cy; o[2] = ex; o[3] = ey;
+        }
+      }
+      // slot: position among the group's obstacles that keep a row, or the caller's own slot
+      const unsigned long long bal = __ballot(keep);
+      const unsigned gm = (unsigned)(bal >> (grp * G)) & (G == 32 ? 0xffffffffu : 0xffffu);
+      const int pos = compact ? n_rel + __popc(gm & ((1u << lane) - 1u)) : j;
+      if (keep) {
+        lds_obs[pos][0] = ex; lds_obs[pos][1] = ey; lds_obs[pos][2] = bb; lds_obs[pos][3] = kfirst;
+        lds_perm[pos] = j;
+      }
+      n_rel += __popc(gm);
+    }
+    if (!compact) n_rel = P.n_obs;                 // slots by the caller's numbering: all of them count
+  }
+  wave_sync();
+  F.front_flag = *lds_flag_g;
+  F.n_rel = n_rel;
+  // the ballast row: n_d copies of 0.q <= s_bar
+  F.n_ball = MAXOBS > 0 ? gsum<G>(nd_l) : 0.0;
+  F.s_ball = F.n_ball > 0.0 ? gsum<G>(ss_l) / F.n_ball : 0.0;
+  return F;
+}
+
+// The solve of one problem on one group of G lanes, from the front end's half-spaces: NOBS_L LDCBF row slots per lane
+// (obstacle slots 0 .. 2 NOBS_L - 1 of `obs`).  Output pointers may be null.
+template <int G, int NOBS_L, int NVAR = G>
+__device__ __forceinline__ StepOut step_solve(
+    const KArgs& P, const StepIn& in, const FrontOut<G>& F, const double (*obs)[4], const int* perm,
+    double* __restrict__ U, double* __restrict__ X, double* __restrict__ obj_out, int32_t* __restrict__ status_out,
+    int32_t* __restrict__ iters_out, unsigned long long* __restrict__ active_out,
+    double* __restrict__ diag, WarmIO* __restrict__ warm, int32_t* __restrict__ cost_out) {
   // NVAR = variable slots of the factorisation: G (every lane holds a variable: horizons up to G / 2), or 8 on a 16-lane
   // group for horizons up to 4 -- the reference's default N_horizon = 3, BASELINE config 5 -- where lanes 8..15 hold no
   // variable, their rows of K are 2I and decouple, and the factorisation / substitutions run on the leading 8 x 8 block
@@ -427,15 +568,8 @@ __device__ __forceinline__ StepOut step_body(
   constexpr bool FUSED32 = (G == 32);  // the same on two DPP rows per problem (FactorStep32, solve32_*: row-masked chains)
 #endif
 
-  // a problem's obstacle rings staged in LDS by one coalesced sweep of the group when they fit (n_obs x v_max vertices
-  // <= RING_CAP: the 10 x 5 of BASELINE config 2 do): the edge walk of the closest-point step then reads LDS instead
-  // of paying one global-memory latency per edge
-  constexpr int RING_CAP = (G == 16) ? 64 : 256;
-  __shared__ double lds_ring[GPW][MAXOBS > 0 ? RING_CAP : 1][2];
-  __shared__ double lds_obs[GPW][MAXOBS > 0 ? MAXOBS : 1][4];   // eta_x, eta_y, b = eta.c + delta, h0
   __shared__ double lds_P[GPW][LMAX][2][2];                     // P_b blocks of the velocity part of K
   __shared__ unsigned long long lds_act[GPW][MAXWORDS];
-  __shared__ int lds_flag[GPW];
   __shared__ double lds_mu[GPW][2];      // no-progress safeguard: mu of the previous iteration, sigma floor of this one
   __shared__ double lds_sz[GPW][NOBS_S > 0 ? NOBS_S : 1][G][2];   // streamed rows: (s, z) then (s, y); lane-contiguous
 
@@ -456,25 +590,10 @@ __device__ __forceinline__ StepOut step_body(
   const double gx = in.gx, gy = in.gy, foot0 = in.foot0, delta = in.delta;
   const double p0c = c ? p0y : p0x, v0c = c ? v0y : v0x, gc = c ? gy : gx;
 
-  // ---- theta / omega (HumanoidMpc.py:137-160) -------------------------------------------------
-  const double psi = atan2(gy - p0y, gx - p0x);
-  double th_r = 0.0, th_v = 0.0, om_a = 0.0, theta1 = th0, omega0 = 0.0;
-  {
-    double th = th0;
-    if (valid && lane == 0 && theta_out) theta_out[pb * (N + 1)] = th0;
-    for (int k = 0; k < N; ++k) {
-      double w = fmin(fmax(psi - th, -in.omega_max), in.omega_max);
-      double thn = th + w * P.tau;
-      if (k == a) { th_r = th; th_v = thn; om_a = w; }
-      if (k == 0) { theta1 = thn; omega0 = w; }
-      if (valid && lane == 0 && theta_out) { omega_out[pb * N + k] = w; theta_out[pb * (N + 1) + k + 1] = thn; }
-      th = thn;
-    }
-  }
-  // R(theta_a) and W(theta_{a+1}): one sincos per lane (the c = 0 lane of a stage takes theta_a, its partner
-  // theta_{a+1}), exchanged inside the stage
-  double s_own, c_own;
-  sincos(c ? th_v : th_r, &s_own, &c_own);
+  const double th_r = F.th_r, th_v = F.th_v, om_a = F.om_a, theta1 = F.theta1, omega0 = F.omega0;
+  const double s_own = F.s_own, c_own = F.c_own;
+  (void)th_r; (void)th_v;
+  // R(theta_a) and W(theta_{a+1}): the lane's sin / cos (front end) exchanged inside the stage
   const double s_oth = gxor<G, 1>(s_own), c_oth = gxor<G, 1>(c_own);
   const double sr = c ? s_oth : s_own, cr = c ? c_oth : c_own, sv = c ? s_own : s_oth, cv = c ? c_own : c_oth;
   const double foot_r = (a & 1) ? -foot0 : foot0;      // s_v[a]
@@ -490,76 +609,10 @@ __device__ __forceinline__ StepOut step_body(
   const double cm = (c == 0) ? on : 0.0;          // the manoeuvrability row lives on the c = 0 lane of its stage
   const double kap_l = on * kap;
 
-  // ---- obstacles: c_j, eta_j at the current CoM (HumanoidMpc.py:296-319) ----------------------
-  // Presolve (oracle: presolve_ldcbf): every feasible p_k lies within k * reach_step of p_0, so the LDCBF row of obstacle j
-  // at stage k is REDUNDANT -- never active, never violated -- where its value at p_0 exceeds |eta_j| k reach_step by a
-  // margin; such rows leave the problem (kfirst_j = the first stage that keeps its row) and n_d copies of one ballast row
-  // 0.q <= s_bar (their mean slack) keep their averaging effect on mu / sigma in the interior-point phase.  Exact mode, cold
-  // start only: the answer there is the path-independent certified optimum.
-  const bool presolve = !(P.flags & (LIPMPC_FLAG_INTERIOR | LIPMPC_FLAG_NO_PRESOLVE)) && (warm == nullptr || warm->lds == nullptr);
-  double nd_l = 0.0, ss_l = 0.0;          // this lane's share of n_d and of the dropped rows' slack sum
-  if (lane == 0) lds_flag[grp] = 0;
-  const bool staged = MAXOBS > 0 && !c_eta_in && P.n_obs * P.nvert_max <= RING_CAP;     // wave-uniform
-  if (staged) {
-    const double* src = obs_xy + pb * (long)P.n_obs * P.nvert_max * 2;
-    double* dst = &lds_ring[grp][0][0];
-    for (int v = lane; v < P.n_obs * P.nvert_max * 2; v += G) dst[v] = src[v];
-  }
-  wave_sync();
-  if (MAXOBS > 0) {
-    for (int j = lane; j < MAXOBS; j += G) {
-      if (j >= P.n_obs) {      // unused slot: absent (kfirst = +inf), harmless values
-        lds_obs[grp][j][0] = 0.0; lds_obs[grp][j][1] = 0.0; lds_obs[grp][j][2] = 0.0; lds_obs[grp][j][3] = INFINITY;
-        continue;
-      }
-      const long oidx = pb * P.n_obs + j;
-      double cx = 0, cy = 0, ex = 0, ey = 0, bb = 0, h0 = INFINITY;
-      bool there, degen = false;
-      if (c_eta_in) {      // caller-supplied half-spaces (the reference's _get_list_c_and_eta hook): eta = (0,0) = empty slot, NaN = degenerate
-        const double* ce = c_eta_in + oidx * 4;
-        cx = ce[0]; cy = ce[1]; ex = ce[2]; ey = ce[3];
-        there = (ex != 0.0) || (ey != 0.0);
-        degen = (ex != ex) || (ey != ey);       // NaN normal: the producer met degenerate geometry (lipmpc_lidar_c_eta_batch)
-      } else {
-        const int nv = obs_nv[oidx];
-        there = nv > 0;
-        if (there) {
-          const ClosestPoint cp = staged ? closest_point_impl(&lds_ring[grp][j * P.nvert_max][0], nv, p0x, p0y)
-                                         : closest_point_normal(obs_xy + oidx * P.nvert_max * 2, nv, p0x, p0y);
-          cx = cp.cx; cy = cp.cy; ex = cp.ex; ey = cp.ey;
-          degen = cp.degenerate != 0;
-        }
-      }
-      double kfirst = INFINITY;                  // first stage whose row of this obstacle stays in the problem (+inf: empty slot)
-      if (there) {
-#pragma clang fp contract(off)                   // (the same roundings as the oracles: the screening test below compares them)
-        const double ec = ex * cx + ey * cy;
-        bb = ec + delta;
-        h0 = (ex * p0x + ey * p0y) - ec - delta;
-        if (degen) atomicOr(&lds_flag[grp], 2);
-        else if (h0 < -P.k0_tol) atomicOr(&lds_flag[grp], 1);
-        int kf = 1;
-        if (presolve) {
-          const double es = sqrt(ex * ex + ey * ey) * P.reach_step;
-          while (kf <= N && h0 > es * (double)kf + SCREEN_MARGIN) ++kf;
-          nd_l += (double)(kf - 1);
-          ss_l += (double)(kf - 1) * h0;
-        }
-        kfirst = (double)kf;
-      }                                          // nv == 0: empty slot
-      lds_obs[grp][j][0] = ex; lds_obs[grp][j][1] = ey; lds_obs[grp][j][2] = bb; lds_obs[grp][j][3] = kfirst;
-      if (c_eta && valid) {
-        double* o = c_eta + oidx * 4;
-        o[0] = cx; o[1] = cy; o[2] = ex; o[3] = ey;
-      }
-    }
-  }
-  wave_sync();
-  const int front_flag = lds_flag[grp];
+  const int front_flag = F.front_flag;
   // the ballast row: n_d copies of 0.q <= s_bar, hosted in the manoeuvrability slot of lane 1 (a = 0, c = 1: that slot holds no
   // row there and its direction coefficient cm is zero), weighted n_d in the two sums it enters
-  const double n_ball = MAXOBS > 0 ? gsum<G>(nd_l) : 0.0;
-  const double s_ball = n_ball > 0.0 ? gsum<G>(ss_l) / n_ball : 0.0;
+  const double n_ball = F.n_ball, s_ball = F.s_ball;
   const bool ball = (lane == 1) && (n_ball > 0.0);
   const double ball_w = ball ? n_ball - 1.0 : 0.0;       // the slot counts once by itself
 
@@ -570,19 +623,19 @@ __device__ __forceinline__ StepOut step_body(
 #pragma unroll
   for (int t = 0; t < NOBS_R; ++t) {
     const int j = 2 * t + c;
-    const bool there = var_on && ((double)(a + 1) >= lds_obs[grp][j][3]);
-    const double ex = lds_obs[grp][j][0], ey = lds_obs[grp][j][1];
+    const bool there = var_on && ((double)(a + 1) >= obs[j][3]);
+    const double ex = obs[j][0], ey = obs[j][1];
     oo[t] = there ? (c ? ey : ex) : 0.0; oq[t] = there ? (c ? ex : ey) : 0.0;
-    ob[t] = there ? lds_obs[grp][j][2] : -1.0;
+    ob[t] = there ? obs[j][2] : -1.0;
     pres.set(R_CBF + t, there);
   }
   // streamed rows: presence bits, accessors
   unsigned pbits = 0u;
 #pragma unroll
   for (int t = 0; t < NOBS_S; ++t)
-    if (var_on && (double)(a + 1) >= lds_obs[grp][2 * t + c][3]) pbits |= 1u << t;
+    if (var_on && (double)(a + 1) >= obs[2 * t + c][3]) pbits |= 1u << t;
   auto s_obs = [&](int t, double& ex, double& ey, double& b) {
-    const double* o = lds_obs[grp][2 * t + c];
+    const double* o = obs[2 * t + c];
     ex = o[0]; ey = o[1]; b = o[2];
   };
   auto s_pm = [&](int t) -> double { return ((pbits >> t) & 1u) ? 1.0 : 0.0; };
@@ -1164,9 +1217,9 @@ __device__ __forceinline__ StepOut step_body(
     if (i == R_VU) return 5 * N + 4 * a + c;
     if (i == R_VL) return 5 * N + 4 * a + 2 + c;
     if (i == R_M) return 4 * N + a;
-    return 9 * N + (a + 1) * P.n_obs + 2 * (i - R_CBF) + c;
+    return 9 * N + (a + 1) * P.n_obs + perm[2 * (i - R_CBF) + c];
   };
-  auto ci_s = [&](int t) -> int { return 9 * N + (a + 1) * P.n_obs + 2 * t + c; };
+  auto ci_s = [&](int t) -> int { return 9 * N + (a + 1) * P.n_obs + perm[2 * t + c]; };
 
   // diagnostics: identification margin min |log(z/(1e5 s))| and final mu of the interior-point phase;
   // initial working set z > 1e5 s
@@ -1488,6 +1541,50 @@ __device__ __forceinline__ StepOut step_body(
   return r;
 }
 
+// The whole MPC step of one problem on one group of G lanes: front end, then the SMALLEST solver body that holds the
+// obstacles which still have a row after the presolve (2, 7 or the handle's NOBS_L row slots per lane; the wave takes the
+// body its neediest group needs).  On the BASELINE fields a step keeps 0-3 of 10 obstacles (N = 8) or 0-6 of 50 (N = 16), so
+// the 2-slot body solves what the 5-slot / the 25-slot streamed body was sized for.  DISPATCH = false (the closed-loop kernel,
+// whose callers run the interior mode, where every present obstacle keeps its rows): the handle's body only -- one body per
+// kernel keeps that kernel's register allocation.  Output pointers may be null.
+template <int G, int NOBS_L, int NVAR = G, bool DISPATCH = true>
+__device__ __forceinline__ StepOut step_body(
+    const KArgs& P, const StepIn& in, const double* __restrict__ obs_xy, const int32_t* __restrict__ obs_nv,
+    double* __restrict__ U, double* __restrict__ X, double* __restrict__ theta_out,
+    double* __restrict__ omega_out, double* __restrict__ obj_out, int32_t* __restrict__ status_out,
+    int32_t* __restrict__ iters_out, unsigned long long* __restrict__ active_out, double* __restrict__ c_eta,
+    double* __restrict__ diag, const double* __restrict__ c_eta_in = nullptr, WarmIO* __restrict__ warm = nullptr,
+    int32_t* __restrict__ cost_out = nullptr) {
+  constexpr int GPW = 64 / G;
+  constexpr int MAXOBS = 2 * NOBS_L;
+  // a problem's obstacle rings staged in LDS by one coalesced sweep of the group when they fit (n_obs x v_max vertices
+  // <= RING_CAP: the 10 x 5 of BASELINE config 2 do): the edge walk of the closest-point step then reads LDS instead
+  // of paying one global-memory latency per edge
+  constexpr int RING_CAP = (G == 16) ? 64 : 256;
+  __shared__ double lds_ring[GPW][MAXOBS > 0 ? RING_CAP : 1][2];
+  __shared__ double lds_obs[GPW][MAXOBS > 0 ? MAXOBS : 1][4];   // eta_x, eta_y, b = eta.c + delta, kfirst
+  __shared__ int lds_perm[GPW][MAXOBS > 0 ? MAXOBS : 1];
+  __shared__ int lds_flag[GPW];
+  __shared__ int lds_need[GPW];
+  const int grp = threadIdx.x / G;
+  const bool cold = (warm == nullptr) || (warm->lds == nullptr);
+  const FrontOut<G> F = front_end<G, MAXOBS>(P, in, obs_xy, obs_nv, theta_out, omega_out, c_eta, c_eta_in, cold, lds_ring[grp],
+                                             lds_obs[grp], lds_perm[grp], &lds_flag[grp]);
+#define LIPMPC_SOLVE(NL) step_solve<G, NL, NVAR>(P, in, F, lds_obs[grp], lds_perm[grp], U, X, obj_out, status_out, iters_out, active_out, diag, warm, cost_out)
+  if constexpr (DISPATCH && NOBS_L > 2) {
+    if ((threadIdx.x & (G - 1)) == 0) lds_need[grp] = (F.n_rel + 1) >> 1;      // row slots per lane this group's obstacles need
+    wave_sync();
+    int need = 0;
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) need = max(need, lds_need[g]);
+    need = __builtin_amdgcn_readfirstlane(need);
+    if (need <= 2) return LIPMPC_SOLVE(2);
+    if constexpr (NOBS_L > 7) { if (need <= 7) return LIPMPC_SOLVE(7); }
+  }
+  return LIPMPC_SOLVE(NOBS_L);
+#undef LIPMPC_SOLVE
+}
+
 // ------------------------------------------------------------------------------------------
 // kernel 1: one MPC step for B problems (lipmpc_plan_step_batch)
 // ------------------------------------------------------------------------------------------
@@ -1578,7 +1675,7 @@ __global__ __launch_bounds__(WAVE) void rollout_kernel(
       const bool is_mpc = (k % mpc_step) == 0;
       double theta1, omega0;
       if (is_mpc) {     // group-uniform (k and mpc_step are wave-uniform)
-        const StepOut r = step_body<G, NOBS_L, NVAR>(P, in, obs_xy, obs_nv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+        const StepOut r = step_body<G, NOBS_L, NVAR, false>(P, in, obs_xy, obs_nv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                                                nullptr, nullptr, nullptr, nullptr, nullptr, &ws);
         if (use_warm) ws.have = true;             // (a failed solve ends the run anyway)
         st_last = r.status;

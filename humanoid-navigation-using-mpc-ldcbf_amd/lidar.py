@@ -192,6 +192,8 @@ class HumanoidMPCUnknownEnvironment(HumanoidMPC):
         self._big_sensor = None
         self._gen = None if noise_seed is None else torch.Generator(device=self._sensor.device).manual_seed(int(noise_seed))
         self.list_inferred_obstacles = []
+        self.list_lidar_readings = []          # per scan: `resolution` entries, None or the noisy hit (x, y) -- the reference's
+                                               # range_finder readings (HumanoidMPCUnknownEnvironment.py:66, HumanoidMpc.py:86)
 
     def _sense(self, x_k: float, y_k: float):
         """One scan at (x_k, y_k): (c_eta [n,4], rings) of the inferred obstacles, c / eta assembled in the scan's launch."""
@@ -200,7 +202,7 @@ class HumanoidMPCUnknownEnvironment(HumanoidMPC):
         noise = None
         if self._gen is not None:
             noise = NOISE_STD * torch.randn((1, self.lidar_resolution, 2), dtype=torch.float64, device=dev, generator=self._gen)
-        out = self._sensor.sense(st, noise, c_eta=True)
+        out = self._sensor.sense(st, noise, c_eta=True, with_debug=True)
         torch.cuda.synchronize(dev)
         if int(out["overflow"][0]):
             # more clusters / longer hulls than the default slots: scan again (same noise) into the largest layout the
@@ -209,7 +211,7 @@ class HumanoidMPCUnknownEnvironment(HumanoidMPC):
             if self._big_sensor is None:
                 self._big_sensor = LidarSensor(self._env, self.lidar_range, self.lidar_resolution, n_obs_max=50, v_max=32,
                                                device=self._device)
-            out = self._big_sensor.sense(st, noise, c_eta=True)
+            out = self._big_sensor.sense(st, noise, c_eta=True, with_debug=True)
             torch.cuda.synchronize(dev)
             if int(out["overflow"][0]):
                 raise RuntimeError("LiDAR scan inferred more obstacles / hull vertices than the solver holds (50 x 32)")
@@ -218,6 +220,8 @@ class HumanoidMPCUnknownEnvironment(HumanoidMPC):
         xy = out["obs_xy"][0].cpu().numpy()
         rings = [xy[j, :nv[j]].copy() for j in range(n)]
         self.list_inferred_obstacles.append(rings)
+        hits = out["hits"][0].cpu().numpy()
+        self.list_lidar_readings.append([None if h[0] != h[0] else (float(h[0]), float(h[1])) for h in hits])
         return out["c_eta"][0, :n].cpu().numpy(), rings
 
     def _get_list_c_and_eta(self, x_k: float, y_k: float):

@@ -52,20 +52,41 @@ def test_every_instantiation_is_independent_of_leftover_state(N, n_obs):
     goal = np.tile([[12.5, 12.5]], (B, 1))
     args = (_dev(st, torch.float64), _dev(goal, torch.float64), _dev(foot, torch.int8), _dev(xy, torch.float64), _dev(nv, torch.int32), None)
     outs = []
-    for flags in (0, lipmpc.FLAG_INTERIOR | lipmpc.FLAG_WARM_START):
+    # flags 0: presolve + the smallest solver body that holds the remaining obstacles; NO_PRESOLVE: every row, i.e. the body
+    # the handle was sized for; INTERIOR | WARM_START: the closed-loop form.  Per flag set also the other entry points of the
+    # step kernel: given half-spaces (lipmpc_plan_step_batch_c_eta) and a launch on a cost-ordered schedule.
+    flag_sets = (0, lipmpc.FLAG_NO_PRESOLVE, lipmpc.FLAG_INTERIOR | lipmpc.FLAG_WARM_START)
+    for flags in flag_sets:
         sv = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5, flags=flags))
+        sv_s = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5, flags=flags))
+        sv_s.set_schedule(B)
+        sv_s.plan_step_batch(*args)                              # leaves the order the poisoned launches run in
         for pat in PATTERNS:
             torch.cuda.synchronize()
             assert pz.lipmpc_poison(pat, 15) == 0
-            o = sv.plan_step_batch(*args, with_diag=True)
+            o = sv.plan_step_batch(*args, with_diag=True, with_c_eta=n_obs > 0)
             ro = sv.rollout(*args, k_max=4, mpc_step=1)
             torch.cuda.synchronize()
-            outs.append((flags, pat, {k: v.cpu().numpy() for k, v in o.items()}, {k: v.cpu().numpy() for k, v in ro.items()}))
-    for flags in (0, lipmpc.FLAG_INTERIOR | lipmpc.FLAG_WARM_START):
+            assert pz.lipmpc_poison(pat, 15) == 0
+            o_s = sv_s.plan_step_batch(*args)
+            torch.cuda.synchronize()
+            rec = {k: v.cpu().numpy() for k, v in o.items()}
+            rec["U_sched"] = o_s["U"].cpu().numpy()
+            if n_obs > 0:
+                assert pz.lipmpc_poison(pat, 15) == 0
+                o_c = sv.plan_step_batch_c_eta(args[0], args[1], args[2], o["c_eta"], with_diag=True)
+                torch.cuda.synchronize()
+                rec["U_c_eta"], rec["status_c_eta"] = o_c["U"].cpu().numpy(), o_c["status"].cpu().numpy()
+            outs.append((flags, pat, rec, {k: v.cpu().numpy() for k, v in ro.items()}))
+    for flags in flag_sets:
         ref = [x for x in outs if x[0] == flags]
         assert np.isin(ref[0][2]["status"], (0, 4)).mean() > 0.5             # the batch is solvable at all
+        assert np.array_equal(ref[0][2]["U_sched"], ref[0][2]["U"], equal_nan=True)      # the order changes nothing
+        if n_obs > 0:                                                        # given half-spaces = the ring front end's own
+            assert np.array_equal(ref[0][2]["status_c_eta"], ref[0][2]["status"])
+            assert np.array_equal(ref[0][2]["U_c_eta"], ref[0][2]["U"], equal_nan=True)
         for _, pat, o, ro in ref[1:]:
-            for k in ("U", "X", "status", "iters", "active", "obj", "diag"):
+            for k in ("U", "X", "status", "iters", "active", "obj", "diag", "U_sched") + (("U_c_eta", "status_c_eta") if n_obs > 0 else ()):
                 assert np.array_equal(o[k], ref[0][2][k], equal_nan=True), (N, n_obs, flags, hex(pat), k)
             n = ro["n_steps"]
             assert np.array_equal(n, ref[0][3]["n_steps"]) and np.array_equal(ro["total_iters"], ref[0][3]["total_iters"])
@@ -88,10 +109,14 @@ def test_lidar_kernel_is_independent_of_leftover_state(golden_dir):
         assert pz.lipmpc_poison(pat, 15) == 0
         o = sensor.sense(_dev(st, torch.float64), _dev(noise, torch.float64), with_debug=True)
         torch.cuda.synchronize()
-        outs.append({k: v.cpu().numpy() for k, v in o.items()})
+        assert pz.lipmpc_poison(pat, 15) == 0
+        oc = sensor.sense(_dev(st, torch.float64), _dev(noise, torch.float64), c_eta=True, rings=False)      # the fused constraint assembly
+        torch.cuda.synchronize()
+        outs.append({**{k: v.cpu().numpy() for k, v in o.items()}, "c_eta": oc["c_eta"].cpu().numpy(), "n_inferred_c": oc["n_inferred"].cpu().numpy()})
     for o in outs[1:]:
-        for k in ("n_inferred", "overflow", "obs_nv", "labels"):
+        for k in ("n_inferred", "overflow", "obs_nv", "labels", "n_inferred_c"):
             assert np.array_equal(o[k], outs[0][k]), k
+        assert np.array_equal(o["c_eta"], outs[0]["c_eta"], equal_nan=True)
         assert np.array_equal(o["hits"], outs[0]["hits"], equal_nan=True)
         for b in range(B):
             for j in range(int(o["n_inferred"][b])):

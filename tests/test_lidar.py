@@ -206,6 +206,38 @@ def test_gpu_unknown_environment_step_end_to_end(golden_dir):
 
 
 @pytest.mark.gpu
+def test_gpu_unknown_environment_class_between_mpc_samples(golden_dir, monkeypatch):
+    """sampling_time = 0.1 (mpc_step = 4): like the reference, the class scans on EVERY sample (its lists grow per sample,
+    HumanoidMpc.py:387 / HumanoidMPCUnknownEnvironment.py:65-66) but solves only on MPC samples (:415-417), between which
+    the CoM stands still and only the heading moves (:443-447); list_lidar_readings mirrors range_finder's readings
+    (`resolution` entries, None or the noisy hit)."""
+    torch = pytest.importorskip("torch")
+    import lipmpc
+    d = np.load(os.path.join(golden_dir, "lidar_golden.npz"))
+    _, rings, _ = _case(d, 0)
+    mpc = lipmpc.HumanoidMPCUnknownEnvironment(goal=(5, 5), obstacles=rings, N_horizon=3, N_mpc_timesteps=4, sampling_time=0.1,
+                                               init_state=(-0.8, 0, -0.8, 0, 0.7), verbosity=0, lidar_range=1.5, noise_seed=1)
+    solves = []
+    plan = lipmpc.HumanoidMPC._plan
+    monkeypatch.setattr(lipmpc.HumanoidMPC, "_plan", lambda self, st, s0: (solves.append(1), plan(self, st, s0))[1])
+    X, U, _ = mpc.run_simulation(None, make_fast_plot=False, fill_animator=False)
+    K = U.shape[1]
+    assert K == 15 and X.shape[1] == 16                       # 4 MPC steps x 4 samples, the reference's truncation drops the last
+    assert len(solves) == 4                                    # one solve per MPC sample, none in between
+    assert len(mpc.list_inferred_obstacles) == 16 and len(mpc.list_lidar_readings) == 16     # one scan per sample
+    for k in range(K):
+        if k % 4 != 0:                                         # between MPC samples: CoM state kept, footstep re-applied
+            assert np.array_equal(X[:4, k + 1], X[:4, k]) and np.array_equal(U[:2, k], U[:2, k - 1])
+        else:
+            assert not np.array_equal(X[:4, k + 1], X[:4, k])
+    assert np.all(np.diff(X[4]) != 0.0)                         # the heading moves on every sample
+    rd = mpc.list_lidar_readings[0]
+    assert len(rd) == 360 and any(r is None for r in rd) and any(r is not None for r in rd)
+    pts = np.array([r for r in rd if r is not None])
+    assert pts.shape[1] == 2 and np.all(np.hypot(pts[:, 0] + 0.8, pts[:, 1] + 0.8) < 1.5 + 0.1)     # hits within the LiDAR range of the robot
+
+
+@pytest.mark.gpu
 def test_gpu_unknown_environment_class_and_throughput(golden_dir):
     """The drop-in HumanoidMPCUnknownEnvironment walks a CROWDED map it only sees through the scanner, and the
     batched pipeline (scan + step for 4096 robots on one map) is timed for the record."""
