@@ -386,6 +386,8 @@ def main():
         }
         if world == 1:
             res["rollout"] = rollout_throughput(lipmpc, walker, obs_xy, obs_nv, goal, delta, dev)
+        if world == 1 and args.all_configs:
+            # the opt-in warm start of the closed loop: fewer iterations, more live state, not faster in wall time
             warm_walker = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5,
                                                                    flags=lipmpc.FLAG_INTERIOR | lipmpc.FLAG_WARM_START), local_rank)
             res["rollout_warm_start"] = rollout_throughput(lipmpc, warm_walker, obs_xy, obs_nv, goal, delta, dev)
