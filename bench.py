@@ -291,19 +291,23 @@ def main():
     torch.cuda.synchronize(dev)
     barrier()
     torch.cuda.synchronize(dev)
-    # kernel duration per launch: events on the stream the kernel is launched on (torch's current)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # Launch duration: ONE pair of HIP events around the K timed launches, on the stream the kernel is launched on (torch's
+    # current) -- the average per launch includes the gap to the next launch, so it is an upper bound of the kernel's own
+    # duration (the rocprofv3 trace in profiles/ gives that).  An event pair around EVERY launch, as rounds 1-2 had it, puts
+    # two more packets between consecutive kernels and cost 10-15 us per step of the timed region itself
+    # (tools/graph_gap.py: 0.116 ms per step without them against 0.131 with).
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for k in range(args.steps):
-        ev[k][0].record()
         step(k)
-        ev[k][1].record()
+    ev1.record()
     torch.cuda.synchronize(dev)
     barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
 
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kern_ms = ev0.elapsed_time(ev1) / args.steps
     order_detail = None
     if scheduled:
         order_detail = launch_order_figures(solver, args.steps, B, (state, foot), (state_b, foot_b), goal, obs_xy, obs_nv, delta, out, dev)
@@ -366,6 +370,7 @@ def main():
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          **roofline_frac(achieved, peak), "traffic": traffic,
                          "kernel": "plan_step_kernel", "kernel_ms": kern_ms,
+                         "kernel_ms_is": "HIP-event span of the timed region / steps (includes the gap between launches)",
                          "flops_per_launch_algorithmic": flops_launch,
                          "executed_fp64_flops_per_launch": executed,
                          "executed_tflops": (executed / (kern_ms * 1e-3) / 1e12) if executed else None,

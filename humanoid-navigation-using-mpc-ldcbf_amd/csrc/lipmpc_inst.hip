@@ -12,8 +12,13 @@ void launch_plan_step(const KArgs& k, long B, const double* state, const double*
                       const double* c_eta_in, int32_t* sched, const int32_t* overflow_in, hipStream_t stream) {
   constexpr int GPW = WAVE / G;
   const unsigned blocks = (unsigned)((B + GPW - 1) / GPW);
-  hipLaunchKernelGGL((plan_step_kernel<G, NOBS_L, NVAR>), dim3(blocks), dim3(WAVE), 0, stream, k, B, state, goal, first_foot,
-                     delta, obs_xy, obs_nv, U, X, theta, omega, obj, status, iters, active, c_eta, diag, bounds, c_eta_in, sched, overflow_in);
+  // exact mode with the presolve: the kernel with the small solver bodies; otherwise the handle's body alone
+  if (k.flags & (LIPMPC_FLAG_INTERIOR | LIPMPC_FLAG_NO_PRESOLVE))
+    hipLaunchKernelGGL((plan_step_kernel<G, NOBS_L, NVAR, false>), dim3(blocks), dim3(WAVE), 0, stream, k, B, state, goal, first_foot,
+                       delta, obs_xy, obs_nv, U, X, theta, omega, obj, status, iters, active, c_eta, diag, bounds, c_eta_in, sched, overflow_in);
+  else
+    hipLaunchKernelGGL((plan_step_kernel<G, NOBS_L, NVAR, true>), dim3(blocks), dim3(WAVE), 0, stream, k, B, state, goal, first_foot,
+                       delta, obs_xy, obs_nv, U, X, theta, omega, obj, status, iters, active, c_eta, diag, bounds, c_eta_in, sched, overflow_in);
 }
 
 template void launch_plan_step<INST_G, INST_NL, INST_NV>(const KArgs&, long, const double*, const double*, const int8_t*,

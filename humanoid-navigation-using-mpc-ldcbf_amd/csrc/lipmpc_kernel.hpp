@@ -538,7 +538,7 @@ __device__ __forceinline__ FrontOut<G> front_end(
 
 // The solve of one problem on one group of G lanes, from the front end's half-spaces: NOBS_L LDCBF row slots per lane
 // (obstacle slots 0 .. 2 NOBS_L - 1 of `obs`).  Output pointers may be null.
-template <int G, int NOBS_L, int NVAR = G>
+template <int G, int NOBS_L, int NVAR = G, bool LEAN = false>
 __device__ __forceinline__ StepOut step_solve(
     const KArgs& P, const StepIn& in, const FrontOut<G>& F, const double (*obs)[4], const int* perm,
     double* __restrict__ U, double* __restrict__ X, double* __restrict__ obj_out, int32_t* __restrict__ status_out,
@@ -567,6 +567,10 @@ __device__ __forceinline__ StepOut step_solve(
   constexpr bool FUSED = (G == 16);    // one-instruction substitution / elimination steps (fmac_bcast)
   constexpr bool FUSED32 = (G == 32);  // the same on two DPP rows per problem (FactorStep32, solve32_*: row-masked chains)
 #endif
+  // the fused substitution chains keep 2 x 31 coefficients per lane next to the factor: only the body with two row slots per
+  // lane has the registers for them (with 5 or more slots, or inside the closed-loop kernel, they spill to scratch: those
+  // keep the unfused substitution)
+  constexpr bool FUSED32_SOLVE = FUSED32 && NOBS_L <= 2 && !LEAN;
 
   __shared__ double lds_P[GPW][LMAX][2][2];                     // P_b blocks of the velocity part of K
   __shared__ unsigned long long lds_act[GPW][MAXWORDS];
@@ -755,7 +759,7 @@ __device__ __forceinline__ StepOut step_solve(
   };
   // G = 16: the triangular factors in the form the fused substitution steps want them (solve):
   //   Xl[j] = -Lt[l][j] / p_j on lanes l > j, 0 elsewhere;  Yu[j] = -Lt[j][l] / p_l ... = -ipiv_l S_l[j] on lanes l < j, 0 elsewhere
-  double Xl[(FUSED || FUSED32) ? NV : 1], Yu[(FUSED || FUSED32) ? NV : 1];
+  double Xl[(FUSED || FUSED32_SOLVE) ? NV : 1], Yu[(FUSED || FUSED32_SOLVE) ? NV : 1];
   auto factor = [&]() -> bool {
     bool ok = true;
     const int ln = fresh(lane);
@@ -774,7 +778,7 @@ __device__ __forceinline__ StepOut step_solve(
         const double ip = fast_rcp(pj);
         ipiv = (ln == j) ? ip : ipiv;
         const double ng = zero_unless(ln > j, Krow[j] * -ip);
-        Xl[j] = ng;
+        if constexpr (FUSED32_SOLVE) Xl[j] = ng;
         FactorStep32<j>::run(Krow, cA, cB, ng);
       } else if constexpr (FUSED) {
         const double pj = gbcast<G, j>(Krow[j]);
@@ -814,7 +818,7 @@ __device__ __forceinline__ StepOut step_solve(
         });
       }
     });
-    if constexpr (FUSED || FUSED32) {
+    if constexpr (FUSED || FUSED32_SOLVE) {
       const double nip = -ipiv;
       static_for<1, NV>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -831,7 +835,7 @@ __device__ __forceinline__ StepOut step_solve(
       dpp_fence();
       b = solve_forward_chain(b, Xl);
       return solve_backward_chain(b * ipiv, Yu);
-    } else if constexpr (FUSED32) {
+    } else if constexpr (FUSED32_SOLVE) {
       // The same recurrences on two DPP rows, the substitution chain inside one row at a time (row_mask): columns 0..15
       // among the lanes of the low row, the high row catches up on those 16 columns after ONE cross-row exchange of the
       // finished values, columns 16..31 inside the high row; and the mirror image backwards.  Xl / Yu hold the
@@ -1547,7 +1551,7 @@ __device__ __forceinline__ StepOut step_solve(
 // the 2-slot body solves what the 5-slot / the 25-slot streamed body was sized for.  DISPATCH = false (the closed-loop kernel,
 // whose callers run the interior mode, where every present obstacle keeps its rows): the handle's body only -- one body per
 // kernel keeps that kernel's register allocation.  Output pointers may be null.
-template <int G, int NOBS_L, int NVAR = G, bool DISPATCH = true>
+template <int G, int NOBS_L, int NVAR = G, bool DISPATCH = true, bool LEAN = false>
 __device__ __forceinline__ StepOut step_body(
     const KArgs& P, const StepIn& in, const double* __restrict__ obs_xy, const int32_t* __restrict__ obs_nv,
     double* __restrict__ U, double* __restrict__ X, double* __restrict__ theta_out,
@@ -1570,7 +1574,7 @@ __device__ __forceinline__ StepOut step_body(
   const bool cold = (warm == nullptr) || (warm->lds == nullptr);
   const FrontOut<G> F = front_end<G, MAXOBS>(P, in, obs_xy, obs_nv, theta_out, omega_out, c_eta, c_eta_in, cold, lds_ring[grp],
                                              lds_obs[grp], lds_perm[grp], &lds_flag[grp]);
-#define LIPMPC_SOLVE(NL) step_solve<G, NL, NVAR>(P, in, F, lds_obs[grp], lds_perm[grp], U, X, obj_out, status_out, iters_out, active_out, diag, warm, cost_out)
+#define LIPMPC_SOLVE(NL) step_solve<G, NL, NVAR, LEAN>(P, in, F, lds_obs[grp], lds_perm[grp], U, X, obj_out, status_out, iters_out, active_out, diag, warm, cost_out)
   if constexpr (DISPATCH && NOBS_L > 2) {
     if ((threadIdx.x & (G - 1)) == 0) lds_need[grp] = (F.n_rel + 1) >> 1;      // row slots per lane this group's obstacles need
     wave_sync();
@@ -1588,7 +1592,11 @@ __device__ __forceinline__ StepOut step_body(
 // ------------------------------------------------------------------------------------------
 // kernel 1: one MPC step for B problems (lipmpc_plan_step_batch)
 // ------------------------------------------------------------------------------------------
-template <int G, int NOBS_L, int NVAR>
+// DISPATCH: the kernel holds the small solver bodies next to the handle's own and a wave picks the smallest that fits (exact
+// mode with the presolve); false: the handle's body alone (interior mode / LIPMPC_FLAG_NO_PRESOLVE, where every present
+// obstacle keeps its rows -- and where the streamed body keeps the register allocation it has when it is alone: inlined next
+// to the small bodies it spills into its row sweeps, 59 instead of 36 us per iteration at N = 16 / 50 obstacles).
+template <int G, int NOBS_L, int NVAR, bool DISPATCH>
 __global__ __launch_bounds__(WAVE) void plan_step_kernel(
     KArgs P, long B, const double* __restrict__ state, const double* __restrict__ goal,
     const int8_t* __restrict__ first_foot, const double* __restrict__ delta_in,
@@ -1622,8 +1630,8 @@ __global__ __launch_bounds__(WAVE) void plan_step_kernel(
   in.foot0 = (double)first_foot[pb];
   in.delta = delta_in ? delta_in[pb] : 0.0;
   in.sensor_overflow = overflow_in && overflow_in[pb] != 0;
-  step_body<G, NOBS_L, NVAR>(P, in, obs_xy, obs_nv, U, X, theta_out, omega_out, obj_out, status_out, iters_out, active_out,
-                             c_eta, diag, c_eta_in, nullptr, sched ? sched + SCHED_ORDER + B : nullptr);
+  step_body<G, NOBS_L, NVAR, DISPATCH>(P, in, obs_xy, obs_nv, U, X, theta_out, omega_out, obj_out, status_out, iters_out, active_out,
+                                       c_eta, diag, c_eta_in, nullptr, sched ? sched + SCHED_ORDER + B : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1675,7 +1683,7 @@ __global__ __launch_bounds__(WAVE) void rollout_kernel(
       const bool is_mpc = (k % mpc_step) == 0;
       double theta1, omega0;
       if (is_mpc) {     // group-uniform (k and mpc_step are wave-uniform)
-        const StepOut r = step_body<G, NOBS_L, NVAR, false>(P, in, obs_xy, obs_nv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+        const StepOut r = step_body<G, NOBS_L, NVAR, false, true>(P, in, obs_xy, obs_nv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                                                nullptr, nullptr, nullptr, nullptr, nullptr, &ws);
         if (use_warm) ws.have = true;             // (a failed solve ends the run anyway)
         st_last = r.status;

@@ -304,8 +304,12 @@ static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, cons
       h[m] = -bb[j];
       ++m;
     }
+  /* ballast: ONE zero row 0.q <= s_bar standing for n_d identical copies (they evolve identically: weight n_d in the two
+   * sums a row's complementarity product enters, mu and mu_aff); interior-point phase only */
   const int m_real = m;
-  for (int i = 0; i < n_ballast; ++i) { NEWROW(-1); h[m] = s_ballast; ++m; }     /* ballast rows: interior-point phase only */
+  if (n_ballast > 0) { NEWROW(-1); h[m] = s_ballast; ++m; }
+  const double m_count = (double)(m_real + n_ballast);
+  const double w_ball = (double)n_ballast;
 #undef NEWROW
   double g[NMAXV], q[NMAXV], rd[NMAXV], dq[NMAXV], tmp[NMAXV];
   for (int k = 0; k < N; ++k) { g[2 * k] = goal[0]; g[2 * k + 1] = goal[1]; q[2 * k] = p0[0]; q[2 * k + 1] = p0[1]; }
@@ -325,10 +329,10 @@ static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, cons
     for (int i = 0; i < m; ++i) {
       rp[i] = t[i] + s[i] - h[i];
       rpmax = fmax(rpmax, fabs(rp[i]));
-      mu += s[i] * z[i];
+      mu += ((i >= m_real) ? w_ball : 1.0) * (s[i] * z[i]);
       zmax = fmax(zmax, z[i]);
     }
-    mu /= m;
+    mu /= m_count;
     for (int i = 0; i < n; ++i) qmax = fmax(qmax, fabs(q[i]));
     if (rpmax <= tol && mu <= tol) { status = LIPMPC_STATUS_SOLVED; break; }
     if (it == P->max_iter) break;
@@ -350,8 +354,8 @@ static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, cons
     for (int i = 0; i < m; ++i) { dsa[i] = -rp[i] - t[i]; dza[i] = -(s[i] * z[i] + z[i] * dsa[i]) / s[i]; }
     double a_aff = fmin(1.0, fmin(max_step(s, dsa, m), max_step(z, dza, m)));
     double mu_aff = 0.0;
-    for (int i = 0; i < m; ++i) mu_aff += (s[i] + a_aff * dsa[i]) * (z[i] + a_aff * dza[i]);
-    mu_aff /= m;
+    for (int i = 0; i < m; ++i) mu_aff += ((i >= m_real) ? w_ball : 1.0) * ((s[i] + a_aff * dsa[i]) * (z[i] + a_aff * dza[i]));
+    mu_aff /= m_count;
     double ratio = mu_aff / mu, sigma = ratio * ratio * ratio;
     if (it >= IPM_SLOW_FROM) {
       double ramp = fmin(1.0, fmax(0.0, (mu / mu_prev - IPM_SLOW_RATIO) * (1.0 / (1.0 - IPM_SLOW_RATIO))));
