@@ -11,10 +11,14 @@
 // problem's structure (rotation blocks, the alternating-sum velocity map, per-stage 2x2 LDCBF
 // blocks), so a problem's live state is n + ~3 m doubles in registers.  For large obstacle sets
 // (more than 7 LDCBF rows per lane) those rows are STREAMED instead: (s, z) per row in LDS, everything
-// else recomputed in each pass (step_body, STREAM).  Horizons up to 4 run the factorisation on 8 variable
-// slots (NVAR = 8).  Two kernels share the body: plan_step_kernel (one step for B problems, optionally in the
-// cost order of the previous launch: lipmpc_set_schedule) and rollout_kernel (the whole closed loop per
-// robot, one launch).
+// else recomputed in each pass (step_solve, STREAM).  Horizons up to 4 run the factorisation on 8 variable
+// slots (NVAR = 8).
+// A step = front_end (theta / omega, closest point and normal per obstacle, presolve of the LDCBF rows the leg-reach rows
+// make redundant, compaction of the obstacles that still have a row) + step_solve<G, NOBS_L, NVAR> (interior point +
+// certified primal active-set finish on NOBS_L row slots per lane); step_body picks the body: in the exact mode with the
+// presolve the smallest of {2, 7, the handle's} slots that holds the wave's neediest problem.  Kernels: plan_step_kernel
+// (one step for B problems, optionally in the cost order of the previous launch: lipmpc_set_schedule; DISPATCH = with /
+// without the small bodies) and rollout_kernel (the whole closed loop per robot, one launch).
 //
 // Reference semantics followed (HumanoidNavigation/...):
 //   theta/omega            MPC/HumanoidMpc.py:137-160
