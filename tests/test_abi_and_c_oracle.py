@@ -186,3 +186,31 @@ def test_synthetic_fields_follow_the_generator_rules():
                           - (bb[:, 1] - a[:, 1]) * (np.roll(bb, -1, 0)[:, 0] - a[:, 0]) > 0)     # strictly convex, CCW
             for q in polys[:i]:
                 assert not synth._sat_intersect(p, q)
+
+
+@pytest.mark.timeout(300)
+def test_headline_kernel_resource_report():
+    """Tripwire for the failure class of round 1 (a kernel reading a register it never wrote, under hundreds of SGPR spills):
+    the compiler's resource report of the headline instantiation (plan_step_kernel<16,5,16,*>: BASELINE config 2) must show no
+    scratch, no VGPR spill to memory and SGPR spills within the recorded bound.  hipcc cross-compiles without a GPU."""
+    import re
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "humanoid-navigation-using-mpc-ldcbf_amd", "csrc", "lipmpc_inst.hip")
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DINST_G=16", "-DINST_NL=5", "-DINST_NV=16",
+                        "-c", src, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = re.split(r"remark: Function Name: ", r.stderr)[1:]
+    seen = 0
+    for blk in blocks:
+        name = blk.split()[0]
+        if "plan_step_kernel" not in name:
+            continue
+        seen += 1
+        val = lambda key: int(re.search(key + r"[^:]*: (\d+)", blk).group(1))
+        assert val("ScratchSize") == 0, (name, val("ScratchSize"))
+        assert val("SGPRs Spill") <= 120, (name, val("SGPRs Spill"))
+        assert val("Occupancy") == 1
+    assert seen == 2                      # the dispatching kernel and the plain one
