@@ -1600,8 +1600,13 @@ __device__ __forceinline__ StepOut step_body(
 // mode with the presolve); false: the handle's body alone (interior mode / LIPMPC_FLAG_NO_PRESOLVE, where every present
 // obstacle keeps its rows -- and where the streamed body keeps the register allocation it has when it is alone: inlined next
 // to the small bodies it spills into its row sweeps, 59 instead of 36 us per iteration at N = 16 / 50 obstacles).
+#ifdef LIPMPC_WAVES2      // dev experiment: two resident waves per SIMD (256 registers per wave)
+#define LIPMPC_OCC __attribute__((amdgpu_waves_per_eu(2, 2)))
+#else
+#define LIPMPC_OCC
+#endif
 template <int G, int NOBS_L, int NVAR, bool DISPATCH>
-__global__ __launch_bounds__(WAVE) void plan_step_kernel(
+__global__ __launch_bounds__(WAVE) LIPMPC_OCC void plan_step_kernel(
     KArgs P, long B, const double* __restrict__ state, const double* __restrict__ goal,
     const int8_t* __restrict__ first_foot, const double* __restrict__ delta_in,
     const double* __restrict__ obs_xy, const int32_t* __restrict__ obs_nv,
