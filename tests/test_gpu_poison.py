@@ -94,6 +94,41 @@ def test_every_instantiation_is_independent_of_leftover_state(N, n_obs):
                 assert np.array_equal(ro["X_pred"][b, : n[b] + 1], ref[0][3]["X_pred"][b, : n[b] + 1]), (N, n_obs, flags, hex(pat), b)
 
 
+@pytest.mark.parametrize("N,n_obs", [(8, 10), (8, 22), (12, 14), (16, 30)])
+def test_every_solver_body_is_independent_of_leftover_state(N, n_obs):
+    """The dispatching step kernel runs the 2-slot, the 7-slot or the handle's own solver body depending on how many obstacles
+    keep a row: robots inside a ring of 0..n_obs small obstacles send waves to each of them, under the three register / LDS
+    fill patterns, with bit-identical outputs."""
+    pz = _poison_lib()
+    rng = np.random.default_rng(11 * N + n_obs)
+    B = 128
+    xy = np.zeros((B, n_obs, 5, 2)); nv = np.full((B, n_obs), 3, np.int32)
+    st = np.zeros((B, 5)); st[:, 0] = rng.uniform(2, 8, B); st[:, 2] = rng.uniform(2, 8, B); st[:, 4] = rng.uniform(-3, 3, B)
+    st[:, 3] = np.where(rng.random(B) < 0.5, 0.2, -0.2)
+    foot = np.where(st[:, 3] > 0, 1, -1).astype(np.int8)
+    for b in range(B):
+        near = (b * (n_obs + 1)) // B                            # 0 .. n_obs obstacles within reach, in blocks of robots
+        for j in range(n_obs):
+            rad = rng.uniform(0.35, 0.18 * N + 0.2) if j < near else rng.uniform(0.18 * N + 1.0, 0.18 * N + 6.0)
+            ang, a0 = rng.uniform(0, 2 * np.pi), rng.uniform(0, 2 * np.pi)
+            c = np.array([st[b, 0] + rad * np.cos(ang), st[b, 2] + rad * np.sin(ang)])
+            xy[b, j, :3] = c + 0.08 * np.array([[np.cos(a0 + t), np.sin(a0 + t)] for t in (0.0, 2.1, 4.2)])
+    goal = st[:, [0, 2]] + rng.uniform(-6, 6, (B, 2))
+    args = (_dev(st, torch.float64), _dev(goal, torch.float64), _dev(foot, torch.int8), _dev(xy, torch.float64), _dev(nv, torch.int32), None)
+    sv = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5))
+    outs = []
+    for pat in PATTERNS:
+        torch.cuda.synchronize()
+        assert pz.lipmpc_poison(pat, 15) == 0
+        o = sv.plan_step_batch(*args, with_diag=True)
+        torch.cuda.synchronize()
+        outs.append({k: v.cpu().numpy() for k, v in o.items()})
+    assert np.isin(outs[0]["status"], (0, 4)).mean() > 0.3
+    for o in outs[1:]:
+        for k in ("U", "X", "status", "iters", "active", "obj", "diag"):
+            assert np.array_equal(o[k], outs[0][k], equal_nan=True), (N, n_obs, k)
+
+
 def test_lidar_kernel_is_independent_of_leftover_state(golden_dir):
     pz = _poison_lib()
     d = np.load(os.path.join(golden_dir, "lidar_golden.npz"))
