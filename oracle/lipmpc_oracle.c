@@ -5,7 +5,9 @@
  * It is a line-for-line C port of oracle/lipmpc_oracle.py (same start point, step rule, stop test,
  * active-set finish), deliberately DENSE: the constraint matrix G (m x n) is materialised and
  * K = 2I + G^T D G is formed with m n (n+1)/2 multiply-adds, i.e. exactly the algorithmic work
- * SURVEY.md §8(d) prices (F_iter).  The HIP kernel never forms G; agreement between the two is
+ * SURVEY.md §8(d) prices (F_iter) on the rows that are in the solve -- all of them with
+ * LIPMPC_FLAG_NO_PRESOLVE, the rows the presolve keeps otherwise (lipmpc_oracle.py: presolve_ldcbf; the
+ * ballast is one weighted zero row here).  The HIP kernel never forms G; agreement between the two is
  * therefore a check of the kernel's structured operators, not a tautology.
  *
  * Reference lines followed (HumanoidNavigation/...):
