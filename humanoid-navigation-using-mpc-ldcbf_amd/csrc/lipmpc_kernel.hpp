@@ -16,7 +16,7 @@
 // A step = front_end (theta / omega, closest point and normal per obstacle, presolve of the LDCBF rows the leg-reach rows
 // make redundant, compaction of the obstacles that still have a row) + step_solve<G, NOBS_L, NVAR> (interior point +
 // certified primal active-set finish on NOBS_L row slots per lane); step_body picks the body: in the exact mode with the
-// presolve the smallest of {2, 7, the handle's} slots that holds the wave's neediest problem.  Kernels: plan_step_kernel
+// presolve the smallest of {1, 2, 7, the handle's} slots that holds the wave's neediest problem.  Kernels: plan_step_kernel
 // (one step for B problems, optionally in the cost order of the previous launch: lipmpc_set_schedule; DISPATCH = with /
 // without the small bodies) and rollout_kernel (the whole closed loop per robot, one launch).
 //
@@ -1550,7 +1550,7 @@ __device__ __forceinline__ StepOut step_solve(
 }
 
 // The whole MPC step of one problem on one group of G lanes: front end, then the SMALLEST solver body that holds the
-// obstacles which still have a row after the presolve (2, 7 or the handle's NOBS_L row slots per lane; the wave takes the
+// obstacles which still have a row after the presolve (1, 2, 7 or the handle's NOBS_L row slots per lane; the wave takes the
 // body its neediest group needs).  On the BASELINE fields a step keeps 0-3 of 10 obstacles (N = 8) or 0-6 of 50 (N = 16), so
 // the 2-slot body solves what the 5-slot / the 25-slot streamed body was sized for.  DISPATCH = false (the closed-loop kernel,
 // whose callers run the interior mode, where every present obstacle keeps its rows): the handle's body only -- one body per
@@ -1579,14 +1579,15 @@ __device__ __forceinline__ StepOut step_body(
   const FrontOut<G> F = front_end<G, MAXOBS>(P, in, obs_xy, obs_nv, theta_out, omega_out, c_eta, c_eta_in, cold, lds_ring[grp],
                                              lds_obs[grp], lds_perm[grp], &lds_flag[grp]);
 #define LIPMPC_SOLVE(NL) step_solve<G, NL, NVAR, LEAN>(P, in, F, lds_obs[grp], lds_perm[grp], U, X, obj_out, status_out, iters_out, active_out, diag, warm, cost_out)
-  if constexpr (DISPATCH && NOBS_L > 2) {
+  if constexpr (DISPATCH && NOBS_L > 1) {
     if ((threadIdx.x & (G - 1)) == 0) lds_need[grp] = (F.n_rel + 1) >> 1;      // row slots per lane this group's obstacles need
     wave_sync();
     int need = 0;
 #pragma unroll
     for (int g = 0; g < GPW; ++g) need = max(need, lds_need[g]);
     need = __builtin_amdgcn_readfirstlane(need);
-    if (need <= 2) return LIPMPC_SOLVE(2);
+    if (need <= 1) return LIPMPC_SOLVE(1);
+    if constexpr (NOBS_L > 2) { if (need <= 2) return LIPMPC_SOLVE(2); }
     if constexpr (NOBS_L > 7) { if (need <= 7) return LIPMPC_SOLVE(7); }
   }
   return LIPMPC_SOLVE(NOBS_L);

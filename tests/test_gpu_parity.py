@@ -716,7 +716,7 @@ def test_fuzz_odd_inputs_against_c_oracle(N, n_obs):
 
 @pytest.mark.parametrize("N,n_obs", [(8, 10), (8, 14), (6, 22), (12, 9), (16, 14), (16, 30)])
 def test_crowded_robots_reach_every_solver_body(N, n_obs):
-    """Which solver body a wave runs depends on how many obstacles keep a row after the presolve (2, 7 or the handle's row
+    """Which solver body a wave runs depends on how many obstacles keep a row after the presolve (1, 2, 7 or the handle's row
     slots per lane).  Robots in the middle of a ring of small obstacles -- 0 to n_obs of them within reach, a different number
     per robot -- send waves to every body of the dispatching kernel; statuses, footsteps and decisive active sets against the
     C oracle, and bit-identical answers from the kernel that keeps every row in the handle's own body."""
