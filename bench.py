@@ -314,7 +314,7 @@ def main():
         order_detail["one_step_stale_order"] = B * args.steps / elapsed
     # the answers of the batch itself, with the certificate margins the CPU check filters on (outside the timed region:
     # the identification margin costs logarithms)
-    out = solver.plan_step_batch(state, goal, foot, obs_xy, obs_nv, delta, with_diag=True)
+    out = solver.plan_step_batch(state, goal, foot, obs_xy, obs_nv, delta, with_diag=True, with_working=True)
     torch.cuda.synchronize(dev)
     status = out["status"].cpu().numpy()
     iters = out["iters"].cpu().numpy()
@@ -361,6 +361,7 @@ def main():
                                    "(generate_obstacles distribution), states from closed-loop warm-up, delta in {0,0.3}",
                        "total_batch": total, "batch_rank0": B, "horizon": N, "obstacles": n_obs,
                        "parallelism": f"contiguous batch shards x{world}, no data-path collective",
+                       "counters": dict(sharding.last_gather),
                        "launch_order": ("cost-ordered schedule (lipmpc_set_schedule), each launch placed by the costs of the same robots one "
                                         "MPC step away (the timed launches alternate between two consecutive steps of the batch)") if scheduled else "index order",
                        "launch_order_solves_per_s_rank0": order_detail},
@@ -613,21 +614,20 @@ def cpu_baseline(P, state, goal, foot, obs_xy, obs_nv, delta, out):
         c64 = r64["status"] == 0
         n_unc_cert = int(c64.sum())
         du_unc = float(np.max(np.abs(U[unc][c64] - r64["U"][c64]))) if c64.any() else None
-    # active sets, bit for bit, on the problems whose certificate is decisive on BOTH sides (tests/helpers.py::decisive_mask,
-    # the filter the parity tests use: a weakly active row -- multiplier or slack within 1e-6 of zero -- may legitimately
-    # sit on either side of the set)
+    # active sets, bit for bit, by the parity tests' own check (tests/helpers.py::compare_active_sets): `active` is the primal
+    # tight set of the optimum (slack <= 1e-7, unique), compared on every certified problem but those with a row within 10 x the
+    # distance between the two answers of that tolerance; the finish's working sets where both certificates are decisive
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from helpers import decisive_mask
-    act_g = out["active"].cpu().numpy().view(np.uint64)
-    firm = decisive_mask(ok, out["diag"].cpu().numpy(), r1["diag"])
-    act_mism = int(np.sum(np.any(act_g[firm] != r1["active"][firm], axis=1)))
+    from helpers import compare_active_sets
+    act_info, _ = compare_active_sets(ok, {k: out[k].cpu().numpy() for k in ("U", "X", "active", "working", "diag")}, r1)
     return {"value": done / t_all, "unit": "solves/s", "cores": cores, "kind": "port",
             "sample": f"the same {B}-problem batch x {reps} passes, OpenMP over problems ({cores} threads); "
                       f"single thread: {B / t1:.0f} solves/s",
             "value_1thread": B / t1, "cpu_model": _cpu_model(),
             "max_abs_dU_gpu_vs_cpu": du,
             "status_mismatches": int(np.sum(r1["status"] != out["status"].cpu().numpy())),
-            "active_set_mismatches": act_mism, "active_sets_compared": int(firm.sum()),
+            "active_set_mismatches": act_info["active_mismatch"], "active_sets_compared": act_info["active_compared"],
+            "active_sets_certified_both": int(ok.sum()), "active_sets": act_info,
             "uncertified": int(len(unc)), "uncertified_certified_by_64_round_oracle": n_unc_cert,
             "max_abs_dU_uncertified_vs_certified_optimum": du_unc}
 

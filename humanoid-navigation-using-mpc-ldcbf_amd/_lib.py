@@ -24,6 +24,11 @@ EXPORTS = ("lipmpc_default_params", "lipmpc_create", "lipmpc_destroy", "lipmpc_n
            "lipmpc_active_words", "lipmpc_plan_step_batch", "lipmpc_plan_step_batch_c_eta", "lipmpc_advance_batch", "lipmpc_fleet_update_batch", "lipmpc_rollout_batch", "lipmpc_lidar_sense_batch", "lipmpc_lidar_c_eta_batch", "lipmpc_lidar_schedule_words", "lipmpc_sense_plan_step_batch", "lipmpc_set_schedule", "lipmpc_schedule_words",
            "lipmpc_strerror", "lipmpc_version")
 
+ABI_VERSION = 5          # LIPMPC_ABI_VERSION of include/lipmpc.h this binding is written for
+VARIANT_BASE = 1000      # LIPMPC_VARIANT_BASE: instrumented development builds report ABI_VERSION + this
+DIAG_WORDS = 8           # LIPMPC_DIAG_WORDS
+TIGHT_TOL = 1e-7         # LIPMPC_TIGHT_TOL
+
 _lib = None
 
 
@@ -41,6 +46,16 @@ def load():
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C <package>/csrc)")
     lib = C.CDLL(path)
     vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+    # The argument lists bound below are those of ONE ABI version: a stale or historical build (LIPMPC_LIB) would take every
+    # pointer after an inserted argument shifted by one, and an instrumented variant (version >= LIPMPC_VARIANT_BASE) writes
+    # other buffer shapes.  Refuse both here, before any pointer is handed over; tools that drive a variant on purpose set
+    # LIPMPC_ALLOW_VARIANT=1 and hand in the buffers that variant expects.
+    lib.lipmpc_version.argtypes = []
+    lib.lipmpc_version.restype = i32
+    ver = int(lib.lipmpc_version())
+    if ver != ABI_VERSION and not (ver == ABI_VERSION + VARIANT_BASE and os.environ.get("LIPMPC_ALLOW_VARIANT") == "1"):
+        raise RuntimeError(f"{path}: lipmpc_version() = {ver}, this binding is written for ABI {ABI_VERSION} "
+                           f"(include/lipmpc.h); rebuild the library (make -C <package>/csrc)")
     lib.lipmpc_default_params.argtypes = [C.POINTER(LipmpcParamsC)]
     lib.lipmpc_default_params.restype = i32
     lib.lipmpc_create.argtypes = [C.POINTER(LipmpcParamsC), i32, C.POINTER(vp)]
@@ -51,9 +66,9 @@ def load():
     lib.lipmpc_num_rows.restype = i64
     lib.lipmpc_active_words.argtypes = [C.POINTER(LipmpcParamsC)]
     lib.lipmpc_active_words.restype = i64
-    lib.lipmpc_plan_step_batch.argtypes = [vp, i64] + [vp] * 18
+    lib.lipmpc_plan_step_batch.argtypes = [vp, i64] + [vp] * 19
     lib.lipmpc_plan_step_batch.restype = i32
-    lib.lipmpc_plan_step_batch_c_eta.argtypes = [vp, i64] + [vp] * 17
+    lib.lipmpc_plan_step_batch_c_eta.argtypes = [vp, i64] + [vp] * 18
     lib.lipmpc_plan_step_batch_c_eta.restype = i32
     lib.lipmpc_advance_batch.argtypes = [vp, i64] + [vp] * 6
     lib.lipmpc_advance_batch.restype = i32
@@ -69,7 +84,7 @@ def load():
     lib.lipmpc_lidar_c_eta_batch.restype = i32
     lib.lipmpc_lidar_schedule_words.argtypes = [i64]
     lib.lipmpc_lidar_schedule_words.restype = i64
-    lib.lipmpc_sense_plan_step_batch.argtypes = ([vp, i64] + [C.c_int32] * 4 + [C.c_double, C.c_double, C.c_int32] + [vp] * 23)
+    lib.lipmpc_sense_plan_step_batch.argtypes = ([vp, i64] + [C.c_int32] * 4 + [C.c_double, C.c_double, C.c_int32] + [vp] * 24)
     lib.lipmpc_sense_plan_step_batch.restype = i32
     lib.lipmpc_set_schedule.argtypes = [vp, vp, i64]
     lib.lipmpc_set_schedule.restype = i32

@@ -127,12 +127,13 @@ class HumanoidMPC:
         return (t._get_list_c_and_eta is not HumanoidMPC._get_list_c_and_eta
                 or t._compute_single_lcbf not in (HumanoidMPC._compute_single_lcbf, HumanoidMPCCustomLCBF._compute_single_lcbf))
 
-    def _plan(self, state5, s0):
+    def _plan(self, state5, s0, lists=None):
         """One MPC step.  Stock hooks: rings -> kernel front end.  Overridden hooks: the subclass's (c, eta) lists and
-        its h(x), turned into data for lipmpc_plan_step_batch_c_eta."""
+        its h(x), turned into data for lipmpc_plan_step_batch_c_eta (``lists``: what the hook already returned for this
+        sample -- the closed loop calls it once per sample, before its stop test, as the reference does)."""
         if not self._hooks_overridden():
             return self._plan_rings(state5, s0)
-        list_c, list_eta = self._get_list_c_and_eta(float(state5[0]), float(state5[2]))
+        list_c, list_eta = lists if lists is not None else self._get_list_c_and_eta(float(state5[0]), float(state5[2]))
         rows = []
         lcbf_stock = type(self)._compute_single_lcbf in (HumanoidMPC._compute_single_lcbf, HumanoidMPCCustomLCBF._compute_single_lcbf)
         delta = None
@@ -207,20 +208,21 @@ class HumanoidMPC:
         u_keep = np.zeros(2)
         ch, sh, beta = self._lip()
         k = 0
+        hooked = self._hooks_overridden()
         for k in range(self.num_inputs):
             is_mpc = k % self.mpc_step == 0
+            st = X_pred[:, k].copy()
+            # The reference assembles the LDCBF constraints on EVERY sample, BEFORE its stop test (HumanoidMpc.py:387 vs :392:
+            # a subclass's _get_list_c_and_eta runs, its scan lists grow by one entry also on the sample the run stops at),
+            # but solves only on MPC samples (:415-417)
+            lists = self._get_list_c_and_eta(float(st[0]), float(st[2])) if hooked else None
             if last_obj < 0.05:                                         # :392-393
                 break
-            st = X_pred[:, k].copy()
             step_number = math.floor(k / self.mpc_step)
             if is_mpc:
-                r = self._plan(st, self.s_v[step_number])
+                r = self._plan(st, self.s_v[step_number], lists)
             else:
-                # The reference assembles the LDCBF constraints on EVERY sample (HumanoidMpc.py:387: a subclass's
-                # _get_list_c_and_eta runs, its scan lists grow) but solves only on MPC samples (:415-417); the other samples
-                # advance the heading with the theta / omega recurrence alone (:137-160, 443-447)
-                if self._hooks_overridden():
-                    self._get_list_c_and_eta(float(st[0]), float(st[2]))
+                # the other samples advance the heading with the theta / omega recurrence alone (:137-160, 443-447)
                 th, om = self._theta_omega(st)
                 r = {"theta": th, "omega": om}
             self.precomputed_theta, self.precomputed_omega = r["theta"], r["omega"]

@@ -157,13 +157,13 @@ void lipmpc_destroy(lipmpc_handle* h) { free(h); }
 
 #define LAUNCH(GG, NL, NV)                                                                                     \
   launch_plan_step<GG, NL, NV>(h->k, (long)B, state, goal, first_foot, delta, obs_xy, obs_nv, U, X, theta, omega, obj, \
-                               status, iters, (unsigned long long*)active, c_eta, diag, bounds, c_eta_in, sched, overflow, stream)
+                               status, iters, (unsigned long long*)active, (unsigned long long*)working, c_eta, diag, bounds, c_eta_in, sched, overflow, stream)
 
 static int plan_step_impl(lipmpc_handle* h, int64_t B, const double* state, const double* goal,
                           const int8_t* first_foot, const double* delta, const double* obs_xy,
                           const int32_t* obs_nv, const double* c_eta_in, double* U, double* X, double* theta, double* omega,
-                          double* obj, int32_t* status, int32_t* iters, uint64_t* active, double* c_eta, double* diag,
-                          const double* bounds, const int32_t* overflow, void* hip_stream) {
+                          double* obj, int32_t* status, int32_t* iters, uint64_t* active, uint64_t* working, double* c_eta,
+                          double* diag, const double* bounds, const int32_t* overflow, void* hip_stream) {
   if (!h || B < 0) return LIPMPC_E_ARG;
   if (B == 0) return LIPMPC_OK;
   if (!state || !goal || !first_foot || !U || !X || !theta || !omega || !obj || !status || !iters || !active)
@@ -214,20 +214,20 @@ int64_t lipmpc_schedule_words(int64_t B) { return B < 0 ? LIPMPC_E_ARG : SCHED_O
 int lipmpc_plan_step_batch(lipmpc_handle* h, int64_t B, const double* state, const double* goal,
                            const int8_t* first_foot, const double* delta, const double* obs_xy,
                            const int32_t* obs_nv, double* U, double* X, double* theta, double* omega,
-                           double* obj, int32_t* status, int32_t* iters, uint64_t* active, double* c_eta, double* diag,
-                           const double* bounds, void* hip_stream) {
+                           double* obj, int32_t* status, int32_t* iters, uint64_t* active, uint64_t* working, double* c_eta,
+                           double* diag, const double* bounds, void* hip_stream) {
   return plan_step_impl(h, B, state, goal, first_foot, delta, obs_xy, obs_nv, nullptr, U, X, theta, omega, obj, status, iters,
-                        active, c_eta, diag, bounds, nullptr, hip_stream);
+                        active, working, c_eta, diag, bounds, nullptr, hip_stream);
 }
 
 int lipmpc_plan_step_batch_c_eta(lipmpc_handle* h, int64_t B, const double* state, const double* goal,
                                  const int8_t* first_foot, const double* delta, const double* c_eta_in,
                                  const int32_t* overflow, double* U, double* X, double* theta, double* omega, double* obj,
-                                 int32_t* status, int32_t* iters, uint64_t* active, double* diag, const double* bounds,
-                                 void* hip_stream) {
+                                 int32_t* status, int32_t* iters, uint64_t* active, uint64_t* working, double* diag,
+                                 const double* bounds, void* hip_stream) {
   if (h && h->p.n_obs_max > 0 && !c_eta_in) return LIPMPC_E_ARG;
   return plan_step_impl(h, B, state, goal, first_foot, delta, nullptr, nullptr, c_eta_in, U, X, theta, omega, obj, status,
-                        iters, active, nullptr, diag, bounds, overflow, hip_stream);
+                        iters, active, working, nullptr, diag, bounds, overflow, hip_stream);
 }
 
 #define LAUNCH_RO(GG, NL, NV)                                                                                    \
@@ -280,7 +280,8 @@ int lipmpc_sense_plan_step_batch(lipmpc_handle* h, int64_t B, int32_t resolution
                                  const double* env_xy, const int32_t* env_nv, const double* ray_table, const double* noise,
                                  double* c_eta, int32_t* n_inferred, int32_t* overflow, int32_t* schedule,
                                  double* U, double* X, double* theta, double* omega, double* obj, int32_t* status,
-                                 int32_t* iters, uint64_t* active, double* diag, const double* bounds, void* hip_stream) {
+                                 int32_t* iters, uint64_t* active, uint64_t* working, double* diag, const double* bounds,
+                                 void* hip_stream) {
   if (!h || B < 0) return LIPMPC_E_ARG;
   if (h->p.n_obs_max < 1) return LIPMPC_E_UNSUPPORTED;        // a handle without obstacle slots has nothing to sense into
   if (!c_eta || !goal || !first_foot || !U || !X || !theta || !omega || !obj || !status || !iters || !active) return LIPMPC_E_ARG;
@@ -291,7 +292,7 @@ int lipmpc_sense_plan_step_batch(lipmpc_handle* h, int64_t B, int32_t resolution
   // the scan's overflow flags go to the solve: a robot whose clusters did not fit the obstacle slots gets
   // LIPMPC_STATUS_SENSOR_OVERFLOW and NaN outputs instead of a plan against the truncated list
   return lipmpc_plan_step_batch_c_eta(h, B, state, goal, first_foot, delta, c_eta, overflow, U, X, theta, omega, obj, status, iters,
-                                      active, diag, bounds, hip_stream);
+                                      active, working, diag, bounds, hip_stream);
 }
 
 int lipmpc_advance_batch(lipmpc_handle* h, int64_t B, double* state, int8_t* first_foot, const double* U,
@@ -334,6 +335,10 @@ const char* lipmpc_strerror(int code) {
   }
 }
 
+#ifdef LIPMPC_PHASE_TIMING      // an instrumented build writes phase counters where the product writes diag: not loadable as the product
+int lipmpc_version(void) { return LIPMPC_ABI_VERSION + LIPMPC_VARIANT_BASE; }
+#else
 int lipmpc_version(void) { return LIPMPC_ABI_VERSION; }
+#endif
 
 }  // extern "C"

@@ -8,22 +8,22 @@ template <int G, int NOBS_L, int NVAR>
 void launch_plan_step(const KArgs& k, long B, const double* state, const double* goal, const int8_t* first_foot,
                       const double* delta, const double* obs_xy, const int32_t* obs_nv, double* U, double* X,
                       double* theta, double* omega, double* obj, int32_t* status, int32_t* iters,
-                      unsigned long long* active, double* c_eta, double* diag, const double* bounds,
+                      unsigned long long* active, unsigned long long* working, double* c_eta, double* diag, const double* bounds,
                       const double* c_eta_in, int32_t* sched, const int32_t* overflow_in, hipStream_t stream) {
   constexpr int GPW = WAVE / G;
   const unsigned blocks = (unsigned)((B + GPW - 1) / GPW);
   // exact mode with the presolve: the kernel with the small solver bodies; otherwise the handle's body alone
-  if (k.flags & (LIPMPC_FLAG_INTERIOR | LIPMPC_FLAG_NO_PRESOLVE))
+  if (k.flags & (LIPMPC_FLAG_INTERIOR | LIPMPC_FLAG_NO_PRESOLVE | LIPMPC_FLAG_WARM_START))
     hipLaunchKernelGGL((plan_step_kernel<G, NOBS_L, NVAR, false>), dim3(blocks), dim3(WAVE), 0, stream, k, B, state, goal, first_foot,
-                       delta, obs_xy, obs_nv, U, X, theta, omega, obj, status, iters, active, c_eta, diag, bounds, c_eta_in, sched, overflow_in);
+                       delta, obs_xy, obs_nv, U, X, theta, omega, obj, status, iters, active, working, c_eta, diag, bounds, c_eta_in, sched, overflow_in);
   else
     hipLaunchKernelGGL((plan_step_kernel<G, NOBS_L, NVAR, true>), dim3(blocks), dim3(WAVE), 0, stream, k, B, state, goal, first_foot,
-                       delta, obs_xy, obs_nv, U, X, theta, omega, obj, status, iters, active, c_eta, diag, bounds, c_eta_in, sched, overflow_in);
+                       delta, obs_xy, obs_nv, U, X, theta, omega, obj, status, iters, active, working, c_eta, diag, bounds, c_eta_in, sched, overflow_in);
 }
 
 template void launch_plan_step<INST_G, INST_NL, INST_NV>(const KArgs&, long, const double*, const double*, const int8_t*,
                                                 const double*, const double*, const int32_t*, double*, double*,
-                                                double*, double*, double*, int32_t*, int32_t*, unsigned long long*,
+                                                double*, double*, double*, int32_t*, int32_t*, unsigned long long*, unsigned long long*,
                                                 double*, double*, const double*, const double*, int32_t*, const int32_t*, hipStream_t);
 
 template <int G, int NOBS_L, int NVAR>

@@ -452,11 +452,13 @@ __device__ __forceinline__ FrontOut<G> front_end(
   // Presolve (oracle: presolve_ldcbf): every feasible p_k lies within k * reach_step of p_0, so the LDCBF row of obstacle j
   // at stage k is REDUNDANT -- never active, never violated -- where its value at p_0 exceeds |eta_j| k reach_step by a
   // margin; such rows leave the problem (kfirst_j = the first stage that keeps its row) and n_d copies of one ballast row
-  // 0.q <= s_bar (their mean slack) keep their averaging effect on mu / sigma in the interior-point phase.  Exact mode, cold
-  // start only: the answer there is the path-independent certified optimum.
+  // 0.q <= s_bar (their mean slack) keep their averaging effect on mu / sigma in the interior-point phase.  ONE rule, the same
+  // in both oracles and in the launcher's choice of kernel: the presolve runs unless a flag says the interior iterates matter
+  // (LIPMPC_FLAG_INTERIOR, LIPMPC_FLAG_WARM_START) or turns it off (LIPMPC_FLAG_NO_PRESOLVE) -- whether or not this particular
+  // step actually has a warm start to read.
   // Compaction (cold start only: a warm start parks per-slot state between steps): the obstacles that still have a row move
   // to the leading slots, so that the wave can run the smallest solver body that holds them (step_body).
-  const bool presolve = !(P.flags & (LIPMPC_FLAG_INTERIOR | LIPMPC_FLAG_NO_PRESOLVE)) && cold;
+  const bool presolve = !(P.flags & (LIPMPC_FLAG_INTERIOR | LIPMPC_FLAG_NO_PRESOLVE | LIPMPC_FLAG_WARM_START));
   const bool compact = cold;
   double nd_l = 0.0, ss_l = 0.0;          // this lane's share of n_d and of the dropped rows' slack sum
   if (lane == 0) *lds_flag_g = 0;
@@ -547,6 +549,7 @@ __device__ __forceinline__ StepOut step_solve(
     const KArgs& P, const StepIn& in, const FrontOut<G>& F, const double (*obs)[4], const int* perm,
     double* __restrict__ U, double* __restrict__ X, double* __restrict__ obj_out, int32_t* __restrict__ status_out,
     int32_t* __restrict__ iters_out, unsigned long long* __restrict__ active_out,
+    unsigned long long* __restrict__ working_out,
     double* __restrict__ diag, WarmIO* __restrict__ warm, int32_t* __restrict__ cost_out) {
   // NVAR = variable slots of the factorisation: G (every lane holds a variable: horizons up to G / 2), or 8 on a 16-lane
   // group for horizons up to 4 -- the reference's default N_horizon = 3, BASELINE config 5 -- where lanes 8..15 hold no
@@ -1495,23 +1498,59 @@ __device__ __forceinline__ StepOut step_solve(
   const double u = (q - P.ch * pprev - P.sh_over_beta * vprev) * P.inv_one_minus_ch;
   const double dg = var_on ? (q - gc) : 0.0;
   const double objv = gsum<G>(dg * dg) + (p0x - gx) * (p0x - gx) + (p0y - gy) * (p0y - gy);
-  for (int wi = lane; wi < P.words; wi += G) lds_act[grp][wi] = 0ull;
-  wave_sync();
-  if (have_sol) {
+  // The canonical active set (include/lipmpc.h: `active`): the rows of the problem that are TIGHT at the returned point,
+  // slack <= LIPMPC_TIGHT_TOL -- unique because the minimiser is (the finish's working set, `working`, is one of several
+  // valid certificates at a degenerate vertex) -- and the tightness margin, the distance of the nearest row from changing
+  // sides.  Evaluated the same way in both oracles (oracle/lipmpc_oracle.py: tight_set).
+  RowFlags tight;
+  unsigned tbits = 0u;
+  double tm_l = INFINITY;
+  if (have_sol && X) {
+    slack_values(q);
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-      const int ci = ci_of(i);
-      if (act[i]) atomicOr(&lds_act[grp][ci >> 6], 1ull << (ci & 63));
+      tight.set(i, pres[i] && (slk[i] <= LIPMPC_TIGHT_TOL));
+      tm_l = fmin(tm_l, pres[i] ? fabs(slk[i] - LIPMPC_TIGHT_TOL) : INFINITY);
     }
     if constexpr (STREAM) {
+      const double fx = cx_, fy = cy_;
 #pragma unroll STREAM_UNROLL
       for (int t = 0; t < NOBS_S; ++t) {
-        const int ci = ci_s(t);
-        if ((abits >> t) & 1u) atomicOr(&lds_act[grp][ci >> 6], 1ull << (ci & 63));
+        if ((pbits >> t) & 1u) {
+          double ex, ey, bb;
+          s_obs(t, ex, ey, bb);
+          const double sl = ex * fx + ey * fy - bb;
+          if (sl <= LIPMPC_TIGHT_TOL) tbits |= 1u << t;
+          tm_l = fmin(tm_l, fabs(sl - LIPMPC_TIGHT_TOL));
+        }
       }
     }
   }
-  wave_sync();
+  const double tight_margin = (diag != nullptr) ? gmin<G>(tm_l) : 0.0;
+  // a row set as bits of the group's mask words in LDS, then to the caller's buffer
+  auto put_mask = [&](const RowFlags& rf, unsigned sb, unsigned long long* __restrict__ dst) {
+    for (int wi = lane; wi < P.words; wi += G) lds_act[grp][wi] = 0ull;
+    wave_sync();
+    if (have_sol) {
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const int ci = ci_of(i);
+        if (rf[i]) atomicOr(&lds_act[grp][ci >> 6], 1ull << (ci & 63));
+      }
+      if constexpr (STREAM) {
+#pragma unroll STREAM_UNROLL
+        for (int t = 0; t < NOBS_S; ++t) {
+          const int ci = ci_s(t);
+          if ((sb >> t) & 1u) atomicOr(&lds_act[grp][ci >> 6], 1ull << (ci & 63));
+        }
+      }
+    }
+    wave_sync();
+    if (valid) for (int wi = lane; wi < P.words; wi += G) dst[pb * P.words + wi] = lds_act[grp][wi];
+    wave_sync();
+  };
+  if (X) put_mask(tight, tbits, active_out);
+  if (X && working_out) put_mask(act, abits, working_out);
   if (valid && X) {
     const double nanv = NAN;
     if (var_on) {
@@ -1530,11 +1569,14 @@ __device__ __forceinline__ StepOut step_solve(
       status_out[pb] = status;
       iters_out[pb] = iters;
 #ifndef LIPMPC_PHASE_TIMING
-      if (diag) { diag[pb * 4 + 0] = diag_rounds; diag[pb * 4 + 1] = diag_eres; diag[pb * 4 + 2] = margin; diag[pb * 4 + 3] = diag_cert; }
+      if (diag) {
+        double* dg_ = diag + pb * LIPMPC_DIAG_WORDS;
+        dg_[0] = diag_rounds; dg_[1] = diag_eres; dg_[2] = margin; dg_[3] = diag_cert; dg_[4] = tight_margin;
+        dg_[5] = 0.0; dg_[6] = 0.0; dg_[7] = 0.0;
+      }
 #endif
       if (cost_out) cost_out[pb] = iters + 2 * (int)diag_rounds;      // this problem's weight for the next launch's order (a finish round ~ 1.5-2 iterations)
     }
-    for (int wi = lane; wi < P.words; wi += G) active_out[pb * P.words + wi] = lds_act[grp][wi];
   }
   PH(11)
 #ifdef LIPMPC_PHASE_TIMING
@@ -1560,7 +1602,8 @@ __device__ __forceinline__ StepOut step_body(
     const KArgs& P, const StepIn& in, const double* __restrict__ obs_xy, const int32_t* __restrict__ obs_nv,
     double* __restrict__ U, double* __restrict__ X, double* __restrict__ theta_out,
     double* __restrict__ omega_out, double* __restrict__ obj_out, int32_t* __restrict__ status_out,
-    int32_t* __restrict__ iters_out, unsigned long long* __restrict__ active_out, double* __restrict__ c_eta,
+    int32_t* __restrict__ iters_out, unsigned long long* __restrict__ active_out,
+    unsigned long long* __restrict__ working_out, double* __restrict__ c_eta,
     double* __restrict__ diag, const double* __restrict__ c_eta_in = nullptr, WarmIO* __restrict__ warm = nullptr,
     int32_t* __restrict__ cost_out = nullptr) {
   constexpr int GPW = 64 / G;
@@ -1578,7 +1621,7 @@ __device__ __forceinline__ StepOut step_body(
   const bool cold = (warm == nullptr) || (warm->lds == nullptr);
   const FrontOut<G> F = front_end<G, MAXOBS>(P, in, obs_xy, obs_nv, theta_out, omega_out, c_eta, c_eta_in, cold, lds_ring[grp],
                                              lds_obs[grp], lds_perm[grp], &lds_flag[grp]);
-#define LIPMPC_SOLVE(NL) step_solve<G, NL, NVAR, LEAN>(P, in, F, lds_obs[grp], lds_perm[grp], U, X, obj_out, status_out, iters_out, active_out, diag, warm, cost_out)
+#define LIPMPC_SOLVE(NL) step_solve<G, NL, NVAR, LEAN>(P, in, F, lds_obs[grp], lds_perm[grp], U, X, obj_out, status_out, iters_out, active_out, working_out, diag, warm, cost_out)
   if constexpr (DISPATCH && NOBS_L > 1) {
     if ((threadIdx.x & (G - 1)) == 0) lds_need[grp] = (F.n_rel + 1) >> 1;      // row slots per lane this group's obstacles need
     wave_sync();
@@ -1613,7 +1656,8 @@ __global__ __launch_bounds__(WAVE) LIPMPC_OCC void plan_step_kernel(
     const double* __restrict__ obs_xy, const int32_t* __restrict__ obs_nv,
     double* __restrict__ U, double* __restrict__ X, double* __restrict__ theta_out,
     double* __restrict__ omega_out, double* __restrict__ obj_out, int32_t* __restrict__ status_out,
-    int32_t* __restrict__ iters_out, unsigned long long* __restrict__ active_out, double* __restrict__ c_eta,
+    int32_t* __restrict__ iters_out, unsigned long long* __restrict__ active_out,
+    unsigned long long* __restrict__ working_out, double* __restrict__ c_eta,
     double* __restrict__ diag, const double* __restrict__ bounds, const double* __restrict__ c_eta_in,
     int32_t* __restrict__ sched, const int32_t* __restrict__ overflow_in) {
   constexpr int GPW = WAVE / G;
@@ -1641,7 +1685,7 @@ __global__ __launch_bounds__(WAVE) LIPMPC_OCC void plan_step_kernel(
   in.delta = delta_in ? delta_in[pb] : 0.0;
   in.sensor_overflow = overflow_in && overflow_in[pb] != 0;
   step_body<G, NOBS_L, NVAR, DISPATCH>(P, in, obs_xy, obs_nv, U, X, theta_out, omega_out, obj_out, status_out, iters_out, active_out,
-                                       c_eta, diag, c_eta_in, nullptr, sched ? sched + SCHED_ORDER + B : nullptr);
+                                       working_out, c_eta, diag, c_eta_in, nullptr, sched ? sched + SCHED_ORDER + B : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1694,7 +1738,7 @@ __global__ __launch_bounds__(WAVE) void rollout_kernel(
       double theta1, omega0;
       if (is_mpc) {     // group-uniform (k and mpc_step are wave-uniform)
         const StepOut r = step_body<G, NOBS_L, NVAR, false, true>(P, in, obs_xy, obs_nv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                               nullptr, nullptr, nullptr, nullptr, nullptr, &ws);
+                                               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ws);
         if (use_warm) ws.have = true;             // (a failed solve ends the run anyway)
         st_last = r.status;
         it_sum += r.iters;
@@ -1733,7 +1777,7 @@ template <int G, int NOBS_L, int NVAR>
 void launch_plan_step(const KArgs& k, long B, const double* state, const double* goal, const int8_t* first_foot,
                       const double* delta, const double* obs_xy, const int32_t* obs_nv, double* U, double* X,
                       double* theta, double* omega, double* obj, int32_t* status, int32_t* iters,
-                      unsigned long long* active, double* c_eta, double* diag, const double* bounds,
+                      unsigned long long* active, unsigned long long* working, double* c_eta, double* diag, const double* bounds,
                       const double* c_eta_in, int32_t* sched, const int32_t* overflow_in, hipStream_t stream);
 template <int G, int NOBS_L, int NVAR>
 void launch_rollout(const KArgs& k, long B, int k_max, int mpc_step, double stop_obj, const double* state0,

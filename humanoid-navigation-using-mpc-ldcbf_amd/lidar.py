@@ -169,7 +169,7 @@ class LidarSensor:
             _ptr(state), _ptr(goal), _ptr(first_foot), _ptr(delta), _ptr(self.env_xy), _ptr(self.env_nv), _ptr(self.table),
             _ptr(noise), _ptr(sen["c_eta"]), _ptr(sen["n_inferred"]), _ptr(sen["overflow"]), _ptr(schedule),
             _ptr(out["U"]), _ptr(out["X"]), _ptr(out["theta"]), _ptr(out["omega"]), _ptr(out["obj"]), _ptr(out["status"]),
-            _ptr(out["iters"]), _ptr(out["active"]), _ptr(out.get("diag")), _ptr(bounds), C.c_void_p(stream))
+            _ptr(out["iters"]), _ptr(out["active"]), _ptr(out.get("working")), _ptr(out.get("diag")), _ptr(bounds), C.c_void_p(stream))
         _lib.check(rc, "lipmpc_sense_plan_step_batch")
         return sen, out
 

@@ -99,7 +99,7 @@ class BatchedLipMpc:
             self._h = C.c_void_p()
 
     # ---- buffers --------------------------------------------------------------------------------
-    def alloc_outputs(self, B, with_c_eta=False, with_diag=False):
+    def alloc_outputs(self, B, with_c_eta=False, with_diag=False, with_working=False):
         P, dev = self.params, self.device
         f64 = dict(dtype=torch.float64, device=dev)
         out = dict(
@@ -113,7 +113,9 @@ class BatchedLipMpc:
         if with_c_eta:
             out["c_eta"] = torch.empty((B, P.n_obs_max, 4), **f64)
         if with_diag:
-            out["diag"] = torch.empty((B, 4), **f64)
+            out["diag"] = torch.empty((B, _lib.DIAG_WORDS), **f64)
+        if with_working:
+            out["working"] = torch.empty((B, P.active_words), dtype=torch.int64, device=dev)
         return out
 
     def _check_inputs(self, state, goal, first_foot, obs_xy, obs_nv, delta, need_obstacles=True):
@@ -138,29 +140,30 @@ class BatchedLipMpc:
 
     # ---- the hot path -----------------------------------------------------------------------------
     def plan_step_batch(self, state, goal, first_foot, obs_xy=None, obs_nv=None, delta=None, out=None,
-                        with_c_eta=False, with_diag=False, bounds=None):
+                        with_c_eta=False, with_diag=False, bounds=None, with_working=False):
         """state [B,5] (px,vx,py,vy,theta), goal [B,2], first_foot [B] int8 (+1 right / -1 left),
         obs_xy [B,n_obs_max,v_max,2] CCW rings, obs_nv [B,n_obs_max] int32, delta [B] or None,
         bounds [B,4] (V_MAX_x, V_MAX_y, ALPHA, OMEGA_MAX) per problem or None.
-        Returns dict(U,X,theta,omega,obj,status,iters,active[,c_eta]) of device tensors; results are
-        valid once the current stream is synchronised."""
+        Returns dict(U,X,theta,omega,obj,status,iters,active[,c_eta][,diag][,working]) of device tensors; results are
+        valid once the current stream is synchronised.  ``active`` = the rows tight at the optimum (slack <= 1e-7: unique),
+        ``working`` = the rows carrying a multiplier in the finish's certificate (include/lipmpc.h)."""
         B = self._check_inputs(state, goal, first_foot, obs_xy, obs_nv, delta)
         self._check_optional(bounds, (B, 4), torch.float64, "bounds")
         if out is None:
-            out = self.alloc_outputs(B, with_c_eta, with_diag)
+            out = self.alloc_outputs(B, with_c_eta, with_diag, with_working)
         else:
             self._check_outputs(out, B)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = self.lib.lipmpc_plan_step_batch(
             self._h, B, _ptr(state), _ptr(goal), _ptr(first_foot), _ptr(delta), _ptr(obs_xy), _ptr(obs_nv),
             _ptr(out["U"]), _ptr(out["X"]), _ptr(out["theta"]), _ptr(out["omega"]), _ptr(out["obj"]),
-            _ptr(out["status"]), _ptr(out["iters"]), _ptr(out["active"]), _ptr(out.get("c_eta")),
+            _ptr(out["status"]), _ptr(out["iters"]), _ptr(out["active"]), _ptr(out.get("working")), _ptr(out.get("c_eta")),
             _ptr(out.get("diag")), _ptr(bounds), C.c_void_p(stream))
         _lib.check(rc, "lipmpc_plan_step_batch")
         return out
 
     def plan_step_batch_c_eta(self, state, goal, first_foot, c_eta_in, delta=None, out=None, with_diag=False, bounds=None,
-                              overflow=None):
+                              overflow=None, with_working=False):
         """The step with the LDCBF half-spaces given (lipmpc_plan_step_batch_c_eta): c_eta_in [B,n_obs_max,4] =
         (c_x, c_y, eta_x, eta_y) per slot, eta = (0,0) = empty slot; row j of stage k is eta_j.(p_k - c_j) - delta >= 0.
         This is what a subclass overriding the reference's _get_list_c_and_eta / _compute_single_lcbf hooks feeds.
@@ -175,15 +178,15 @@ class BatchedLipMpc:
         self._check_optional(bounds, (B, 4), torch.float64, "bounds")
         self._check_optional(overflow, (B,), torch.int32, "overflow")
         if out is None:
-            out = self.alloc_outputs(B, False, with_diag)
+            out = self.alloc_outputs(B, False, with_diag, with_working)
         else:
             self._check_outputs(out, B)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = self.lib.lipmpc_plan_step_batch_c_eta(
             self._h, B, _ptr(state), _ptr(goal), _ptr(first_foot), _ptr(delta), _ptr(c_eta_in), _ptr(overflow),
             _ptr(out["U"]), _ptr(out["X"]), _ptr(out["theta"]), _ptr(out["omega"]), _ptr(out["obj"]),
-            _ptr(out["status"]), _ptr(out["iters"]), _ptr(out["active"]), _ptr(out.get("diag")), _ptr(bounds),
-            C.c_void_p(stream))
+            _ptr(out["status"]), _ptr(out["iters"]), _ptr(out["active"]), _ptr(out.get("working")), _ptr(out.get("diag")),
+            _ptr(bounds), C.c_void_p(stream))
         _lib.check(rc, "lipmpc_plan_step_batch_c_eta")
         return out
 
@@ -202,7 +205,8 @@ class BatchedLipMpc:
                 raise ValueError(f"out['{k}'] missing")
             self._check_optional(out[k], shape, dt, f"out['{k}']")
         self._check_optional(out.get("c_eta"), (B, self.params.n_obs_max, 4), torch.float64, "out['c_eta']")
-        self._check_optional(out.get("diag"), (B, 4), torch.float64, "out['diag']")
+        self._check_optional(out.get("diag"), (B, _lib.DIAG_WORDS), torch.float64, "out['diag']")
+        self._check_optional(out.get("working"), (B, self.params.active_words), torch.int64, "out['working']")
 
     def advance(self, state, first_foot, out):
         """In place: state <- (A_l x + B_l U[:,0], theta[:,1]), first_foot <- -first_foot for the

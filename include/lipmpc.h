@@ -28,8 +28,20 @@
 extern "C" {
 #endif
 
-#define LIPMPC_ABI_VERSION 4   /* 2: + lipmpc_plan_step_batch_c_eta, LIPMPC_STATUS_SENSOR_OVERFLOW; 3: + lipmpc_lidar_c_eta_batch;
-                                * 4: lipmpc_plan_step_batch_c_eta takes the producer's overflow flags */
+#define LIPMPC_ABI_VERSION 5   /* 2: + lipmpc_plan_step_batch_c_eta, LIPMPC_STATUS_SENSOR_OVERFLOW; 3: + lipmpc_lidar_c_eta_batch;
+                                * 4: lipmpc_plan_step_batch_c_eta takes the producer's overflow flags;
+                                * 5: `active` is the primal tight set of the returned point (LIPMPC_TIGHT_TOL), the finish's
+                                *    working set moves to the new optional output `working`, diag is [B,8],
+                                *    + lipmpc_set_workspace / lipmpc_workspace_bytes */
+/* An instrumented development build (tools/build_variant.sh: phase counters in `diag`, other buffer contracts) reports
+ * LIPMPC_ABI_VERSION + LIPMPC_VARIANT_BASE from lipmpc_version(), so that a loader which checks the version refuses it. */
+#define LIPMPC_VARIANT_BASE 1000
+
+/* `active` bit i: canonical row i is in the problem and TIGHT at the returned point, slack_i(q) = h_i - g_i.q <=
+ * LIPMPC_TIGHT_TOL.  The minimiser of the strictly convex step QP is unique, so this set is unique too -- unlike the set
+ * of rows with a positive multiplier (`working`), which is not at a degenerate vertex (linearly dependent tight rows). */
+#define LIPMPC_TIGHT_TOL 1e-7
+#define LIPMPC_DIAG_WORDS 8
 
 /* per-problem status written to status[b] */
 #define LIPMPC_STATUS_SOLVED       0  /* exact optimum, KKT-certified active set */
@@ -117,20 +129,28 @@ int64_t lipmpc_active_words(const lipmpc_params* p);
  * outputs
  *  U      [B,N,2]    footsteps U_mpc            X [B,N+1,4] predicted states X_mpc
  *  theta  [B,N+1]    omega [B,N]                obj [B] objective incl. the constant k=0 term
- *  status [B]  iters [B]  active [B,lipmpc_active_words]  bit i = canonical row i in the certified active set
+ *  status [B]  iters [B]
+ *  active  [B,lipmpc_active_words]  bit i = canonical row i is tight at the returned point (slack <= LIPMPC_TIGHT_TOL): the
+ *          active set of the optimum in the textbook sense, unique because the optimum is; all zero unless status is SOLVED
+ *          or UNCERTIFIED (there: the tight rows of the interior-point iterate handed out)
+ *  working [B,lipmpc_active_words] or NULL: the working set the certified finish ended on = the rows that carry a positive
+ *          multiplier in its KKT certificate (a subset of `active` up to LIPMPC_TIGHT_TOL; at a degenerate vertex one of
+ *          several valid choices); UNCERTIFIED: the interior-point estimate z_i > 1e5 s_i
  *  c_eta  [B,n_obs_max,4] (c_x,c_y,eta_x,eta_y) or NULL
  *  bounds [B,4] or NULL: per-problem (V_MAX_x, V_MAX_y, ALPHA, OMEGA_MAX) replacing the handle's values —
  *         the knobs the reference's bounds_tuning sweep mutates in `conf` (bounds_tuning.py:17-26)
- *  diag   [B,4] or NULL: (active-set rounds used, final equality residual of the finish,
- *         identification margin min_i |log(z_i/(1e5 s_i))| of the interior-point phase, certificate margin =
- *         min(smallest active multiplier, smallest inactive slack): ~0 flags a weakly determined active set)
+ *  diag   [B,LIPMPC_DIAG_WORDS] or NULL: 0 active-set rounds used, 1 final equality residual of the finish,
+ *         2 identification margin min_i |log(z_i/(1e5 s_i))| of the interior-point phase, 3 certificate margin =
+ *         min(smallest multiplier on the working set, smallest slack outside it): ~0 flags a weakly determined WORKING set,
+ *         4 tightness margin min_i |slack_i - LIPMPC_TIGHT_TOL| over the rows of the problem: how far the nearest row is
+ *         from changing sides in `active` (a perturbation of the answer below it leaves `active` unchanged), 5-7 reserved (0)
  */
 int lipmpc_plan_step_batch(lipmpc_handle* h, int64_t B,
                            const double* state, const double* goal, const int8_t* first_foot,
                            const double* delta, const double* obs_xy, const int32_t* obs_nv,
                            double* U, double* X, double* theta, double* omega, double* obj,
-                           int32_t* status, int32_t* iters, uint64_t* active, double* c_eta, double* diag,
-                           const double* bounds, void* hip_stream);
+                           int32_t* status, int32_t* iters, uint64_t* active, uint64_t* working, double* c_eta,
+                           double* diag, const double* bounds, void* hip_stream);
 
 /* Optional launch order for the step solves of a handle.  A wave lasts as long as the slowest of its problems and a launch
  * of more problems than the GPU holds at once (4096 at N <= 8) runs in rounds, so WHICH problems share a wave and which start
@@ -160,7 +180,7 @@ int lipmpc_plan_step_batch_c_eta(lipmpc_handle* h, int64_t B,
                                  const double* state, const double* goal, const int8_t* first_foot,
                                  const double* delta, const double* c_eta_in, const int32_t* overflow,
                                  double* U, double* X, double* theta, double* omega, double* obj,
-                                 int32_t* status, int32_t* iters, uint64_t* active, double* diag,
+                                 int32_t* status, int32_t* iters, uint64_t* active, uint64_t* working, double* diag,
                                  const double* bounds, void* hip_stream);
 
 /* Closed-loop state advance (HumanoidMpc.py:432-447): for problems with status SOLVED/UNCERTIFIED
@@ -268,7 +288,8 @@ int lipmpc_sense_plan_step_batch(lipmpc_handle* h, int64_t B, int32_t resolution
                                  const double* env_xy, const int32_t* env_nv, const double* ray_table, const double* noise,
                                  double* c_eta, int32_t* n_inferred, int32_t* overflow, int32_t* schedule,
                                  double* U, double* X, double* theta, double* omega, double* obj, int32_t* status,
-                                 int32_t* iters, uint64_t* active, double* diag, const double* bounds, void* hip_stream);
+                                 int32_t* iters, uint64_t* active, uint64_t* working, double* diag, const double* bounds,
+                                 void* hip_stream);
 
 const char* lipmpc_strerror(int code);
 int lipmpc_version(void);

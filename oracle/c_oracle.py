@@ -25,7 +25,7 @@ def load():
             raise RuntimeError(f"{path} missing: run `make -C oracle` (or __graft_entry__.build())")
         _lib = C.CDLL(path)
         _lib.lipmpc_oracle_plan_step_batch.restype = C.c_int
-        _lib.lipmpc_oracle_plan_step_batch.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 18 + [C.c_int]
+        _lib.lipmpc_oracle_plan_step_batch.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 19 + [C.c_int]
         _lib.lipmpc_oracle_max_threads.restype = C.c_int
     return _lib
 
@@ -43,12 +43,14 @@ def plan_step_batch(params, state, goal, first_foot, obs_xy=None, obs_nv=None, d
     c_eta_in = f(c_eta_in, np.float64)
     out = dict(U=np.empty((B, N, 2)), X=np.empty((B, N + 1, 4)), theta=np.empty((B, N + 1)), omega=np.empty((B, N)),
                obj=np.empty(B), status=np.empty(B, np.int32), iters=np.empty(B, np.int32),
-               active=np.zeros((B, words), np.uint64), c_eta=np.zeros((B, max(n_obs, 1), 4)), diag=np.zeros((B, 4)))
+               active=np.zeros((B, words), np.uint64), working=np.zeros((B, words), np.uint64),
+               c_eta=np.zeros((B, max(n_obs, 1), 4)), diag=np.zeros((B, 8)))
     p = lambda a: C.c_void_p(0 if a is None else a.ctypes.data)
     rc = lib.lipmpc_oracle_plan_step_batch(
         C.cast(C.byref(cp), C.c_void_p), B, p(state), p(goal), p(first_foot), p(delta), p(obs_xy), p(obs_nv),
         p(out["U"]), p(out["X"]), p(out["theta"]), p(out["omega"]), p(out["obj"]), p(out["status"]), p(out["iters"]),
-        p(out["active"]), p(out["c_eta"]) if n_obs else p(None), p(out["diag"]), p(bounds), p(c_eta_in), int(n_threads))
+        p(out["active"]), p(out["working"]), p(out["c_eta"]) if n_obs else p(None), p(out["diag"]), p(bounds), p(c_eta_in),
+        int(n_threads))
     if rc != 0:
         raise RuntimeError(f"lipmpc_oracle_plan_step_batch failed ({rc})")
     if not n_obs:

@@ -165,8 +165,8 @@ typedef struct {
 /* One problem.  Layouts as in include/lipmpc.h. */
 static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, const double* st, const double* goal, int foot0, double delta,
                      const double* obs_xy, const int32_t* obs_nv, double* U, double* X, double* theta, double* omega,
-                     double* obj, int32_t* status_out, int32_t* iters_out, uint64_t* active, double* c_eta, double* diag,
-                     const double* c_eta_in) {
+                     double* obj, int32_t* status_out, int32_t* iters_out, uint64_t* active, uint64_t* working, double* c_eta,
+                     double* diag, const double* c_eta_in) {
   lipmpc_params Pl = *P0;   /* per-problem (V_MAX_x, V_MAX_y, ALPHA, OMEGA_MAX) overrides, bounds_tuning.py:17-26 */
   if (bnd) { Pl.v_max_xy[0] = bnd[0]; Pl.v_max_xy[1] = bnd[1]; Pl.alpha = bnd[2]; Pl.omega_max = bnd[3]; }
   const lipmpc_params* P = &Pl;
@@ -175,11 +175,11 @@ static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, cons
   const double kap = beta * sh / (ch - 1.0);
   const int m_tot = 9 * N + (N + 1) * n_obs, words = (m_tot + 63) / 64;
   const double p0[2] = {st[0], st[2]}, v0[2] = {st[1], st[3]};
-  for (int i = 0; i < words; ++i) active[i] = 0;
+  for (int i = 0; i < words; ++i) { active[i] = 0; if (working) working[i] = 0; }
   for (int i = 0; i < N * 2; ++i) U[i] = NAN;
   for (int i = 0; i < (N + 1) * 4; ++i) X[i] = NAN;
   *obj = NAN; *iters_out = 0;
-  if (diag) { diag[0] = 0; diag[1] = 0; diag[2] = INFINITY; diag[3] = 0; }
+  if (diag) { memset(diag, 0, sizeof(double) * LIPMPC_DIAG_WORDS); diag[2] = INFINITY; }
   /* theta / omega (HumanoidMpc.py:137-160) */
   const double psi = atan2(goal[1] - p0[1], goal[0] - p0[0]);
   theta[0] = st[4];
@@ -463,8 +463,20 @@ static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, cons
     else { status = LIPMPC_STATUS_UNCERTIFIED; for (int i = 0; i < m; ++i) act[i] = z[i] > FIN_IDENT * s[i]; }
   }
   *status_out = status;
-  for (int i = 0; i < m; ++i)
-    if (act[i]) active[W->canon[i] >> 6] |= (uint64_t)1 << (W->canon[i] & 63);
+  /* `working`: the set the finish certified with (interior mode / uncertified: the estimate z > 1e5 s);
+   * `active`: the rows TIGHT at the returned point, slack <= LIPMPC_TIGHT_TOL (lipmpc_oracle.py: tight_set) -- unique
+   * because the minimiser is -- and the tightness margin */
+  if (working)
+    for (int i = 0; i < m; ++i)
+      if (act[i]) working[W->canon[i] >> 6] |= (uint64_t)1 << (W->canon[i] & 63);
+  mat_vec(G, q, m, n, t);
+  double tmargin = INFINITY;
+  for (int i = 0; i < m; ++i) {
+    const double sl = h[i] - t[i];
+    if (sl <= LIPMPC_TIGHT_TOL) active[W->canon[i] >> 6] |= (uint64_t)1 << (W->canon[i] & 63);
+    tmargin = fmin(tmargin, fabs(sl - LIPMPC_TIGHT_TOL));
+  }
+  if (diag) diag[4] = tmargin;
 
   /* ---- outputs: X*, U* (recover footsteps), objective incl. the k=0 term ------------------------ */
   double p[17][2], v[17][2];
@@ -487,8 +499,8 @@ static void plan_one(const lipmpc_params* P0, const double* bnd, work_t* W, cons
 int lipmpc_oracle_plan_step_batch(const lipmpc_params* P, int64_t B, const double* state, const double* goal,
                                   const int8_t* first_foot, const double* delta, const double* obs_xy,
                                   const int32_t* obs_nv, double* U, double* X, double* theta, double* omega,
-                                  double* obj, int32_t* status, int32_t* iters, uint64_t* active, double* c_eta,
-                                  double* diag, const double* bounds, const double* c_eta_in, int n_threads) {
+                                  double* obj, int32_t* status, int32_t* iters, uint64_t* active, uint64_t* working,
+                                  double* c_eta, double* diag, const double* bounds, const double* c_eta_in, int n_threads) {
   if (!P || P->N < 1 || P->N > 16 || P->n_obs_max < 0 || P->n_obs_max > 50) return LIPMPC_E_UNSUPPORTED;
   const int N = P->N, n_obs = P->n_obs_max;
   const int64_t words = (9 * N + (N + 1) * n_obs + 63) / 64;
@@ -508,7 +520,8 @@ int lipmpc_oracle_plan_step_batch(const lipmpc_params* P, int64_t B, const doubl
         plan_one(P, bounds ? bounds + b * 4 : NULL, W, state + b * 5, goal + b * 2, (int)first_foot[b], delta ? delta[b] : 0.0,
                  obs_xy ? obs_xy + (size_t)b * n_obs * P->v_max * 2 : NULL, obs_nv ? obs_nv + b * n_obs : NULL,
                  U + b * N * 2, X + b * (N + 1) * 4, theta + b * (N + 1), omega + b * N, obj + b, status + b, iters + b,
-                 active + b * words, c_eta ? c_eta + (size_t)b * n_obs * 4 : NULL, diag ? diag + b * 4 : NULL,
+                 active + b * words, working ? working + b * words : NULL, c_eta ? c_eta + (size_t)b * n_obs * 4 : NULL,
+                 diag ? diag + b * LIPMPC_DIAG_WORDS : NULL,
                  c_eta_in ? c_eta_in + (size_t)b * n_obs * 4 : NULL);
       }
     }

@@ -67,6 +67,10 @@ class Params:
                                     # (= the reference's IPOPT constr_viol_tol, HumanoidMpc.py:99)
     presolve: bool = True           # exact mode: drop the LDCBF rows the leg-reach rows make redundant (presolve_ldcbf);
                                     # False = LIPMPC_FLAG_NO_PRESOLVE
+    warm_start: bool = False        # LIPMPC_FLAG_WARM_START: a closed loop seeds every step with the previous one's result;
+                                    # like the interior mode it keeps every row (ONE rule, also in the kernel and the C port:
+                                    # presolve <=> exact and presolve and not warm_start -- whether or not this particular
+                                    # step has a previous result to read)
 
     @property
     def beta(self):
@@ -86,6 +90,7 @@ class Params:
 
 
 STATUS_SOLVED, STATUS_MAX_ITER, STATUS_INFEASIBLE, STATUS_DEGENERATE, STATUS_UNCERTIFIED = 0, 1, 2, 3, 4
+TIGHT_TOL = 1e-7       # LIPMPC_TIGHT_TOL: a row is ACTIVE (canonical active set) when its slack at the returned point is below this
 SCREEN_MARGIN = 1e-3   # presolve: an LDCBF row is dropped when the leg-reach rows keep it this far from active
 
 
@@ -234,6 +239,18 @@ def list_c_and_eta(x0, obstacles):
 # --------------------------------------------------------------------------------------
 # the step QP, two algebraically identical builders
 # --------------------------------------------------------------------------------------
+
+def tight_set(G, h, q):
+    """The canonical active set of a point q: the rows with slack h_i - g_i.q <= TIGHT_TOL, and the tightness margin
+    min_i |slack_i - TIGHT_TOL| (how far the nearest row is from changing sides).  The minimiser of the strictly convex step
+    QP is unique, so this set is a function of the problem alone -- which the finish's WORKING set (rows with a positive
+    multiplier in its certificate) is not at a degenerate vertex, where linearly dependent tight rows leave the multipliers
+    non-unique.  This is what "active-constraint indices bit-exact" (BASELINE north_star) is checked on."""
+    if G.shape[0] == 0:
+        return np.zeros(0, bool), math.inf
+    slack = h - G @ q
+    return slack <= TIGHT_TOL, float(np.min(np.abs(slack - TIGHT_TOL)))
+
 
 def n_rows(N, n_obs):
     """canonical inequality count: reach 4N | manoeuvr N | vel 4N | LDCBF (N+1) n_obs."""
@@ -718,7 +735,7 @@ def plan_step(state, goal, first_foot, obstacles, delta, P: Params, exact=True, 
     m_tot = n_rows(N, n_obs)
     out = dict(theta=theta, omega=omega, c=cs, eta=etas, status=STATUS_SOLVED, iters=0,
                U=np.full((N, 2), np.nan), X=np.full((N + 1, 4), np.nan), obj=math.nan,
-               active=np.zeros(m_tot, bool), margin=math.inf)
+               active=np.zeros(m_tot, bool), working=np.zeros(m_tot, bool), margin=math.inf, tight_margin=math.inf)
     if degen or not np.all(np.isfinite(etas)):
         out["status"] = STATUS_DEGENERATE
         return out
@@ -732,7 +749,7 @@ def plan_step(state, goal, first_foot, obstacles, delta, P: Params, exact=True, 
     keep = np.ones(m_tot, bool)
     keep[k0] = False
     n_ballast, s_ballast = 0, 0.0
-    if exact and P.presolve and warm is None and n_obs:
+    if exact and P.presolve and not P.warm_start and n_obs:
         red, n_ballast, s_ballast = presolve_ldcbf(x0, cs, etas, delta, P)
         for k in range(1, N + 1):
             keep[9 * N + k * n_obs:9 * N + (k + 1) * n_obs] &= ~red[k - 1]
@@ -752,8 +769,14 @@ def plan_step(state, goal, first_foot, obstacles, delta, P: Params, exact=True, 
     out["X"], out["U"] = X, U
     p = X[:, [0, 2]]
     out["obj"] = float(np.sum((p - np.asarray(goal, float)) ** 2))
+    # `active`: the rows tight at the returned point (canonical, unique); `working`: the set the finish certified with
+    # (interior mode / uncertified: the interior-point estimate z > 1e5 s)
+    tight, out["tight_margin"] = tight_set(Gs, hs, res.q)
+    out["active"][keep] = tight
     if res.active is not None:
-        out["active"][keep] = res.active
+        out["working"][keep] = res.active
+    elif Gs.shape[0]:
+        out["working"][keep] = res.z > FIN_IDENT * res.s
     out["margin"] = res.margin
     out["cert_margin"] = res.cert_margin
     out["q"] = res.q
@@ -776,6 +799,7 @@ def run_closed_loop(goal, obstacles, N_horizon=3, N_mpc_timesteps=100, sampling_
     P = params or Params()
     P.N = N_horizon
     P.sampling_time = sampling_time
+    P.warm_start = bool(warm_start)
     mpc_step = int(P.dt / sampling_time) or 1
     num_inputs = mpc_step * N_mpc_timesteps
     X_pred = np.zeros((5, num_inputs + 1))

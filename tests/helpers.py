@@ -6,22 +6,67 @@ import numpy as np
 import lipmpc_oracle as O
 
 
-CERT_MARGIN = 1e-7     # 100 x FIN_EPS, the sign / violation tolerance the certificate itself decides rows with
+TIGHT_TOL = 1e-7       # LIPMPC_TIGHT_TOL (include/lipmpc.h): `active` bit i <=> slack_i(returned point) <= this
+TIGHT_BAND = 10.0      # a problem's `active` sets are compared unless a row sits within TIGHT_BAND x (distance between the two
+                       # answers) of TIGHT_TOL on either side
+CERT_MARGIN = 1e-8     # working sets (multiplier-based): compared where both certificates hold with at least this margin
+WORKING_DIFF_MARGIN = 1e-7   # ... and a difference ANYWHERE must sit below this certificate margin on one side
+WORKING_DIFF_DU = 1e-6       # ... with the two answers this close in footstep space
+
+
+def _per_problem_gap(a, b):
+    d = np.abs(np.asarray(a, float) - np.asarray(b, float)).reshape(len(a), -1)
+    return np.nan_to_num(np.max(d, axis=1), nan=np.inf)
+
+
+def compare_active_sets(ok, g, ref):
+    """"Active-constraint indices bit-exact" (BASELINE north_star), as the tests and bench.py check it.  g / ref: dicts of
+    numpy arrays (GPU, oracle) with U, X, active [B,words], diag [B,8] and optionally working [B,words]; ok: the problems
+    certified SOLVED on both sides.
+
+    `active` is the PRIMAL TIGHT SET of the returned point (slack <= TIGHT_TOL).  The optimum of the strictly convex step QP
+    is unique, hence so is this set; two solvers whose answers lie d apart can only disagree on a row whose slack lies within
+    ~d of TIGHT_TOL at one of them.  A problem is compared unless such a row exists: tightness margin (diag[:, 4] =
+    min_i |slack_i - TIGHT_TOL|) >= TIGHT_BAND x max(|dX|, |dU|) of that problem on both sides.  (X carries positions and
+    velocities, the quantities the rows are written in.)  The caller asserts zero differences on the compared problems and a
+    floor on their share.
+
+    `working` (rows carrying a multiplier in the finish's certificate) is NOT unique at a degenerate vertex; it is compared
+    where both certificates are decisive (diag[:, 3] >= CERT_MARGIN) and every difference, decisive or not, is reported with
+    the certificate margin and footstep gap it occurs at (caller: below WORKING_DIFF_MARGIN / WORKING_DIFF_DU)."""
+    dU, dX = _per_problem_gap(g["U"], ref["U"]), _per_problem_gap(g["X"], ref["X"])
+    band = TIGHT_BAND * np.maximum(dU, dX)
+    n_ok = max(int(ok.sum()), 1)
+    compared = ok & (g["diag"][:, 4] >= band) & (ref["diag"][:, 4] >= band)
+    diff = np.any(np.ascontiguousarray(g["active"]).view(np.uint64) != np.ascontiguousarray(ref["active"]).view(np.uint64), axis=1)
+    info = dict(active_definition=f"primal tight set, slack <= {TIGHT_TOL:g}", active_compared=int(compared.sum()),
+                active_compared_share=float(compared.sum() / n_ok), active_mismatch=int((diff & compared).sum()),
+                active_mismatch_all_certified=int((diff & ok).sum()),
+                active_excluded_rule=f"a row within {TIGHT_BAND:g} x max(|dX|,|dU|) of the problem from the tolerance, on either side")
+    if "working" in g and "working" in ref:
+        wdiff = ok & np.any(np.ascontiguousarray(g["working"]).view(np.uint64) != np.ascontiguousarray(ref["working"]).view(np.uint64), axis=1)
+        cm = np.minimum(g["diag"][:, 3], ref["diag"][:, 3])
+        dec = ok & (cm >= CERT_MARGIN)
+        info.update(working_decisive_share=float(dec.sum() / n_ok), working_mismatch_decisive=int((wdiff & dec).sum()),
+                    working_mismatch_all_certified=int(wdiff.sum()),
+                    working_mismatch_max_cert_margin=float(cm[wdiff].max()) if wdiff.any() else 0.0,
+                    working_mismatch_max_dU=float(dU[wdiff].max()) if wdiff.any() else 0.0)
+    return info, compared
+
+
+def assert_active_sets(tag, info, min_share):
+    assert info["active_mismatch"] == 0, (tag, info)                       # active-constraint indices bit-exact
+    assert info["active_compared_share"] >= min_share, (tag, info)
+    if "working_mismatch_all_certified" in info:
+        assert info["working_mismatch_max_cert_margin"] < WORKING_DIFF_MARGIN and info["working_mismatch_max_dU"] < WORKING_DIFF_DU, (tag, info)
 
 
 def decisive_mask(ok, diag_a, diag_b, margin=CERT_MARGIN):
-    """Problems on which "active-constraint indices bit-exact" is well posed: certified on both sides (``ok``) with a
-    DECISIVE certificate on both sides -- diag[:, 3] = min(smallest multiplier on the active set, smallest slack outside
-    it) >= margin.  Then strict complementarity holds with room, the optimum's active set is unique and both solvers must
-    report the same bits; below the margin a weakly active row (multiplier ~ 0) or a redundant one (slack ~ 0 outside the
-    set: dependent rows of a degenerate vertex) may legitimately sit on either side.  The margin is a hundred times the
-    tolerance the certificate decides a row with (FIN_EPS = 1e-9: a multiplier above -1e-9 stays, a slack above -1e-9 is
-    feasible): two points that both satisfy the KKT conditions to 1e-9 can lie 3e-8 apart on an ill-conditioned vertex, so a
-    row whose slack is 1.5e-8 at one of them can be active at the other (seen once: problem 1790 of the config-4 batch, row 852,
-    |dU| 1.4e-7 between the two answers).  Measured on the 4096-problem batches of configs 2, 3, 4 and bench.py: every
-    active-set difference between the GPU and the C oracle sits at a margin below 1.5e-8 (profiles/r03_parity.json).
-    The ONE filter used by the parity tests and by bench.py's cpu_baseline check (report the margin, exclude
-    weakly active instances)."""
+    """Problems on which the WORKING sets (rows with a positive multiplier in the finish's certificate) of two solvers must
+    agree: certified on both sides (``ok``) with a decisive certificate on both sides -- diag[:, 3] = min(smallest multiplier
+    on the working set, smallest slack outside it) >= margin.  Below the margin a weakly active row (multiplier ~ 0) or a
+    redundant one (slack ~ 0 outside the set: dependent rows of a degenerate vertex) may legitimately sit on either side,
+    which is why the canonical `active` output is the tight set instead (compare_active_sets)."""
     return ok & (diag_a[:, 3] >= margin) & (diag_b[:, 3] >= margin)
 
 

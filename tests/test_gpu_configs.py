@@ -5,10 +5,12 @@
   config 3  B = 32768, N = 8,  10 obstacles: properties on every problem, C oracle on a 4096 sample, shard independence
   config 4  B = 4096,  N = 16, 50 obstacles: every problem against the C oracle, active sets bit for bit
 
-Bars: footsteps / CoM 1e-5 (north_star; observed ~1e-7), theta / omega 1e-12, statuses and active-constraint indices
-bit-exact on the decisive subset (certificate margin >= 1e-7 on both sides: helpers.decisive_mask, the filter bench.py
-uses too; the excluded share is bounded).  The bars sit a small margin below the observed figures, which every call
-records (helpers.record_parity -> profiles/r03_parity.json via tools/parity_record.sh)."""
+Bars: footsteps / CoM 1e-5 (north_star; observed ~1e-7), theta / omega 1e-12, statuses, and active-constraint indices
+bit-exact: `active` is the primal tight set of the optimum (slack <= 1e-7, unique), compared on every certified problem
+except those with a row within 10 x the distance between the two answers of that tolerance (helpers.compare_active_sets,
+the check bench.py uses too; floors: 0.99 of the certified problems at N = 8, 0.97 at N = 16 / 50 obstacles).  The
+finish's working sets are compared too and every difference is bounded by the certificate margin it occurs at.  Every call
+records its observed figures (helpers.record_parity -> profiles/r04_parity.json via tools/parity_record.sh)."""
 import os
 
 import numpy as np
@@ -19,11 +21,14 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 import lipmpc  # noqa: E402
 import lipmpc_oracle as O  # noqa: E402
-from helpers import (IPOPT_LIKE_TOL, PDF_RUNS, check_pdf_bars, decisive_mask, load_rings, oracle_pdf_run,  # noqa: E402
-                     pdf_compare, pdf_scenario, record_parity)
+from helpers import (IPOPT_LIKE_TOL, PDF_RUNS, assert_active_sets, check_pdf_bars, compare_active_sets, load_rings,  # noqa: E402
+                     oracle_pdf_run, pdf_compare, pdf_scenario, record_parity)
 
 
-MIN_DECISIVE_CFG4 = 0.55      # share of the certified N = 16 / 50-obstacle problems whose certificate is decisive (observed 0.63: r03_parity.json)
+# share of the certified problems whose `active` sets (primal tight sets) are compared bit for bit; the rest have a row
+# within 10 x |answer gap| of the tightness tolerance (helpers.compare_active_sets).  Round-4 review bars, not fitted:
+MIN_ACTIVE_COMPARED = 0.99         # N = 8, 10 obstacles
+MIN_ACTIVE_COMPARED_CFG4 = 0.97    # N = 16, 50 obstacles
 
 
 def _dev(a, dt):
@@ -66,7 +71,7 @@ def _oracle(P, b, idx=None, n_threads=16):
     return c_oracle.plan_step_batch(P, h(b["state"]), h(b["goal"]), h(b["foot"]), xy, nv, h(b["delta"]), n_threads=n_threads)
 
 
-def _compare_with_oracle(tag, P, g, ref, min_decisive, iters_bars=(0.97, 0.999), max_split=0.0005, min_status_equal=0.999):
+def _compare_with_oracle(tag, P, g, ref, min_compared, iters_bars=(0.97, 0.999), max_split=0.0005, min_status_equal=0.999):
     """statuses, footsteps, active sets; returns the observed agreement figures (also printed for the record).
     max_split: tolerated share of problems that one side solves and the other reports failed (a factorisation
     breakdown at cond K ~ 1e16 is decided by the last bit: observed 0 or 1 problem in 4096 at N = 8)."""
@@ -84,23 +89,18 @@ def _compare_with_oracle(tag, P, g, ref, min_decisive, iters_bars=(0.97, 0.999),
     assert np.max(np.abs(g["theta"] - ref["theta"])) < 1e-12 and np.max(np.abs(g["omega"] - ref["omega"])) < 1e-12
     both = solved_g & solved_r
     dit = np.abs(g["iters"][both] - ref["iters"][both])
-    decisive = decisive_mask(ok, g["diag"], ref["diag"])
-    act_g = lipmpc.unpack_active(g["active"], P.num_rows)
-    act_r = lipmpc.unpack_active(ref["active"], P.num_rows)
-    mism = int(np.sum(np.any(act_g[decisive] != act_r[decisive], axis=1)))
-    mism_all = int(np.sum(np.any(act_g[ok] != act_r[ok], axis=1)))         # incl. the weakly determined ones (reported)
+    act_info, _ = compare_active_sets(ok, g, ref)
     info = dict(n=len(gs), status_equal=float(same.mean()), solved_split=int(split.sum()), certified_both=float(ok.mean()),
                 uncertified_gpu=int((gs == 4).sum()), uncertified_oracle=int((rs == 4).sum()), max_dU=du, max_dX=dx,
                 iters_equal=float((dit == 0).mean()), iters_within_1=float((dit <= 1).mean()), iters_max_diff=int(dit.max()),
-                decisive=float(decisive.sum() / max(ok.sum(), 1)), active_mismatch=mism,
-                active_mismatch_all_certified=mism_all)
-    info["bars"] = dict(min_decisive=min_decisive, iters_equal=iters_bars[0], iters_within_1=iters_bars[1], max_split=max_split,
-                        min_status_equal=min_status_equal, max_dU=1e-5, active_mismatch=0)
+                **act_info)
+    info["bars"] = dict(active_compared_share=min_compared, iters_equal=iters_bars[0], iters_within_1=iters_bars[1], max_split=max_split,
+                        min_status_equal=min_status_equal, max_dU=1e-5, active_mismatch=0,
+                        working_mismatch_max_cert_margin=1e-7, working_mismatch_max_dU=1e-6)
     print(tag, info)
     record_parity(tag, info)
-    assert mism == 0, (tag, info)                                          # active-constraint indices bit-exact
+    assert_active_sets(tag, info, min_compared)                            # active-constraint indices bit-exact
     assert same.mean() >= min_status_equal, (tag, info)
-    assert decisive.sum() >= min_decisive * ok.sum(), (tag, info)
     # iteration counts: equal on most problems, off by one where the last residual test sits on the tolerance; the odd
     # problem of the ill-conditioned tail (cond K ~ 1e15 in its last iterations) takes a few more on one side
     assert (dit == 0).mean() >= iters_bars[0] and (dit <= 1).mean() >= iters_bars[1], (tag, info)
@@ -201,11 +201,11 @@ def test_config2_uncertified_answers_are_within_tolerance():
     b = _walked_batch(B, N, n_obs, 9.5, (10.0, 10.0), seed=1234, max_steps=30, delta_mix=True)
     P = lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5)
     sv = lipmpc.BatchedLipMpc(P)
-    out = sv.plan_step_batch(b["state"], b["goal"], b["foot"], b["obs_xy"], b["obs_nv"], b["delta"], with_diag=True)
+    out = sv.plan_step_batch(b["state"], b["goal"], b["foot"], b["obs_xy"], b["obs_nv"], b["delta"], with_diag=True, with_working=True)
     torch.cuda.synchronize()
     g = {k: v.cpu().numpy() for k, v in out.items()}
     ref = _oracle(P, b)
-    _compare_with_oracle("config 2", P, g, ref, min_decisive=0.93, iters_bars=(0.98, 0.999))
+    _compare_with_oracle("config 2", P, g, ref, min_compared=MIN_ACTIVE_COMPARED, iters_bars=(0.98, 0.999))
     _check_uncertified("config 2", P, b, g)
     # A cap of ONE finish round (a caller's tail-latency choice, not the default) leaves ~10 % of the batch UNCERTIFIED,
     # and those answers are plain interior-point iterates: the stop test ignores the dual residual (cond K * eps on
@@ -233,7 +233,8 @@ def test_config3_batch_32768():
     b = _walked_batch(B, N, n_obs, 9.5, (10.0, 10.0), seed=77, max_steps=30, n_fields=8192, delta_mix=True)
     P = lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5)
     sv = lipmpc.BatchedLipMpc(P)
-    out = sv.plan_step_batch(b["state"], b["goal"], b["foot"], b["obs_xy"], b["obs_nv"], b["delta"], with_diag=True, with_c_eta=True)
+    out = sv.plan_step_batch(b["state"], b["goal"], b["foot"], b["obs_xy"], b["obs_nv"], b["delta"], with_diag=True, with_c_eta=True,
+                             with_working=True)
     out2 = sv.plan_step_batch(b["state"], b["goal"], b["foot"], b["obs_xy"], b["obs_nv"], b["delta"])
     torch.cuda.synchronize()
     g = {k: v.cpu().numpy() for k, v in out.items()}
@@ -245,7 +246,7 @@ def test_config3_batch_32768():
     idx = np.sort(np.random.default_rng(5).choice(B, 4096, replace=False))
     ref = _oracle(P, b, idx)
     gi = {k: v[idx] for k, v in g.items()}
-    _compare_with_oracle("config 3 (4096 sample)", P, gi, ref, min_decisive=0.93, iters_bars=(0.98, 0.999))
+    _compare_with_oracle("config 3 (4096 sample)", P, gi, ref, min_compared=MIN_ACTIVE_COMPARED, iters_bars=(0.98, 0.999))
     for world in (2, 4, 8):
         for rank in (0, world - 1):
             lo, hi = sharding.shard_bounds(B, rank, world)
@@ -300,12 +301,13 @@ def test_config4_full_size_against_c_oracle():
     b = _walked_batch(B, N, n_obs, 15.5, (16.0, 16.0), seed=31, max_steps=20, n_fields=1024)
     P = lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5)
     sv = lipmpc.BatchedLipMpc(P)
-    out = sv.plan_step_batch(b["state"], b["goal"], b["foot"], b["obs_xy"], b["obs_nv"], b["delta"], with_diag=True, with_c_eta=True)
+    out = sv.plan_step_batch(b["state"], b["goal"], b["foot"], b["obs_xy"], b["obs_nv"], b["delta"], with_diag=True, with_c_eta=True,
+                             with_working=True)
     torch.cuda.synchronize()
     g = {k: v.cpu().numpy() for k, v in out.items()}
     ref = _oracle(P, b)
     assert np.array_equal(g["c_eta"], ref["c_eta"])
-    info, ok = _compare_with_oracle("config 4", P, g, ref, min_decisive=MIN_DECISIVE_CFG4, iters_bars=(0.88, 0.985), max_split=0.001,
+    info, ok = _compare_with_oracle("config 4", P, g, ref, min_compared=MIN_ACTIVE_COMPARED_CFG4, iters_bars=(0.88, 0.985), max_split=0.001,
                                     min_status_equal=0.995)
     assert info["certified_both"] >= 0.995
     # UNCERTIFIED at this size: the primal active-set rounds of the finish (ratio test: a blocking row is never dependent
@@ -330,10 +332,10 @@ def test_config4_reference_generated_fields(golden_dir):
     foot = np.array([p[2] for p in probs], np.int8); delta = np.array([p[4] for p in probs], float)
     out = lipmpc.BatchedLipMpc(P).plan_step_batch(_dev(st, torch.float64), _dev(goal, torch.float64), _dev(foot, torch.int8),
                                                   _dev(xy, torch.float64), _dev(nv, torch.int32), _dev(delta, torch.float64),
-                                                  with_diag=True, with_c_eta=True)
+                                                  with_diag=True, with_c_eta=True, with_working=True)
     torch.cuda.synchronize()
     g = {k: v.cpu().numpy() for k, v in out.items()}
     ref = c_oracle.plan_step_batch(P, st, goal, foot, xy, nv, delta, n_threads=16)
     assert np.array_equal(g["c_eta"], ref["c_eta"])
-    _compare_with_oracle("config 4 (reference fields)", P, g, ref, min_decisive=MIN_DECISIVE_CFG4, iters_bars=(0.85, 0.97), max_split=0.004,
+    _compare_with_oracle("config 4 (reference fields)", P, g, ref, min_compared=MIN_ACTIVE_COMPARED_CFG4, iters_bars=(0.85, 0.97), max_split=0.004,
                          min_status_equal=0.99)

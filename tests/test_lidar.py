@@ -219,7 +219,7 @@ def test_gpu_unknown_environment_class_between_mpc_samples(golden_dir, monkeypat
                                                init_state=(-0.8, 0, -0.8, 0, 0.7), verbosity=0, lidar_range=1.5, noise_seed=1)
     solves = []
     plan = lipmpc.HumanoidMPC._plan
-    monkeypatch.setattr(lipmpc.HumanoidMPC, "_plan", lambda self, st, s0: (solves.append(1), plan(self, st, s0))[1])
+    monkeypatch.setattr(lipmpc.HumanoidMPC, "_plan", lambda self, st, s0, lists=None: (solves.append(1), plan(self, st, s0, lists))[1])
     X, U, _ = mpc.run_simulation(None, make_fast_plot=False, fill_animator=False)
     K = U.shape[1]
     assert K == 15 and X.shape[1] == 16                       # 4 MPC steps x 4 samples, the reference's truncation drops the last
@@ -235,6 +235,13 @@ def test_gpu_unknown_environment_class_between_mpc_samples(golden_dir, monkeypat
     assert len(rd) == 360 and any(r is None for r in rd) and any(r is not None for r in rd)
     pts = np.array([r for r in rd if r is not None])
     assert pts.shape[1] == 2 and np.all(np.hypot(pts[:, 0] + 0.8, pts[:, 1] + 0.8) < 1.5 + 0.1)     # hits within the LiDAR range of the robot
+    # A run that stops on the objective: the reference assembles the constraints (the subclass hook scans) BEFORE its stop test
+    # (HumanoidMpc.py:387 vs :392), so the sample it stops at is scanned too: one list entry per kept state
+    near = lipmpc.HumanoidMPCUnknownEnvironment(goal=(-0.7, -0.72), obstacles=rings, N_horizon=3, N_mpc_timesteps=30, sampling_time=0.4,
+                                                init_state=(-0.8, 0, -0.8, 0, 0.7), verbosity=0, lidar_range=1.5, noise_seed=1)
+    Xn, Un, _ = near.run_simulation(None, make_fast_plot=False, fill_animator=False)
+    assert 2 <= Xn.shape[1] < 30 and near.last_status in (0, 4)                 # stopped early, on the objective
+    assert len(near.list_inferred_obstacles) == Xn.shape[1] == len(near.list_lidar_readings)
 
 
 @pytest.mark.gpu

@@ -156,3 +156,27 @@ def test_two_rank_bench_with_the_hip_solver():
     assert d["config"]["total_batch"] == 3000 and d["config"]["batch_rank0"] == 1500
     assert abs(d["value"] - 3000 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
     assert d["solver"]["solved_frac"] > 0.95 and "REHEARSAL" in d["data"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_rccl_counter_gather_on_one_gpu():
+    """The RCCL leg of bench.py (init_process_group("nccl", device_id=...) + all_gather of a DEVICE tensor after the timed
+    region) as a fresh child process on the one-GPU box: LIPMPC_FORCE_DIST=1 brings the communicator up at world size 1.
+    One JSON line (RCCL's banner must not reach stdout), n_gpus = 1, and the counter record really went through
+    dist.all_gather with backend nccl on a cuda tensor.  A break in that code would otherwise first show on the 8-GPU run."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LIPMPC_BENCH_REHEARSE")}
+    env.update(LIPMPC_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-other-configs"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["config"]["total_batch"] == 4096
+    c = d["config"]["counters"]
+    assert c["collective"] == "all_gather" and c["backend"] == "nccl" and c["device"].startswith("cuda") and c["world"] == 1
+    assert d["solver"]["solved_frac"] > 0.95 and abs(d["value"] - 4096 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
