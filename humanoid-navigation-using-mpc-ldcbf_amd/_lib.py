@@ -21,7 +21,7 @@ class LipmpcParamsC(C.Structure):
 
 
 EXPORTS = ("lipmpc_default_params", "lipmpc_create", "lipmpc_destroy", "lipmpc_num_rows",
-           "lipmpc_active_words", "lipmpc_plan_step_batch", "lipmpc_plan_step_batch_c_eta", "lipmpc_advance_batch", "lipmpc_fleet_update_batch", "lipmpc_rollout_batch", "lipmpc_lidar_sense_batch", "lipmpc_lidar_c_eta_batch", "lipmpc_lidar_schedule_words", "lipmpc_sense_plan_step_batch", "lipmpc_set_schedule", "lipmpc_schedule_words",
+           "lipmpc_active_words", "lipmpc_plan_step_batch", "lipmpc_plan_step_batch_c_eta", "lipmpc_advance_batch", "lipmpc_fleet_update_batch", "lipmpc_rollout_batch", "lipmpc_lidar_sense_batch", "lipmpc_lidar_c_eta_batch", "lipmpc_lidar_schedule_words", "lipmpc_sense_plan_step_batch", "lipmpc_set_schedule", "lipmpc_schedule_words", "lipmpc_set_workspace", "lipmpc_workspace_bytes",
            "lipmpc_strerror", "lipmpc_version")
 
 ABI_VERSION = 5          # LIPMPC_ABI_VERSION of include/lipmpc.h this binding is written for
@@ -90,6 +90,10 @@ def load():
     lib.lipmpc_set_schedule.restype = i32
     lib.lipmpc_schedule_words.argtypes = [i64]
     lib.lipmpc_schedule_words.restype = i64
+    lib.lipmpc_set_workspace.argtypes = [vp, vp, i64]
+    lib.lipmpc_set_workspace.restype = i32
+    lib.lipmpc_workspace_bytes.argtypes = [vp, i64]
+    lib.lipmpc_workspace_bytes.restype = i64
     lib.lipmpc_strerror.argtypes = [i32]
     lib.lipmpc_strerror.restype = C.c_char_p
     lib.lipmpc_version.argtypes = []

@@ -86,6 +86,44 @@ __global__ __launch_bounds__(1024) void order_by_cost_kernel(long B, int32_t* __
   if (threadIdx.x == 0) sched[SCHED_VALID] = (int32_t)B;
 }
 
+// Index lists per class from the classes: a stable counting sort in one workgroup (every thread owns a contiguous run of
+// problems: per-class counts, an exclusive scan over the threads, then the writes) -- stable, so the lists, and with them which
+// problems share a wave, are a function of the batch alone.
+__global__ __launch_bounds__(1024) void split_bin_kernel(long B, int32_t* __restrict__ ws) {
+  __shared__ int cnt_[SPLIT_CLASSES][1024];
+  __shared__ int base_[SPLIT_CLASSES];
+  const int t = threadIdx.x, T = blockDim.x;
+  const long per = (B + T - 1) / T, lo = min((long)t * per, B), hi = min(lo + per, B);
+  const int32_t* cls = ws + SPLIT_HEAD;
+  int mine[SPLIT_CLASSES];
+#pragma unroll
+  for (int c = 0; c < SPLIT_CLASSES; ++c) mine[c] = 0;
+  for (long i = lo; i < hi; ++i) {
+    const int k = cls[i];
+#pragma unroll
+    for (int c = 0; c < SPLIT_CLASSES; ++c) mine[c] += (k == c) ? 1 : 0;
+  }
+#pragma unroll
+  for (int c = 0; c < SPLIT_CLASSES; ++c) cnt_[c][t] = mine[c];
+  __syncthreads();
+  if (t < SPLIT_CLASSES) {                       // one thread per class scans its row (1024 adds: nothing next to a solve)
+    int run = 0;
+    for (int k = 0; k < T; ++k) { const int v = cnt_[t][k]; cnt_[t][k] = run; run += v; }
+    base_[t] = run;
+    ws[t] = run;
+  }
+  __syncthreads();
+  int pos[SPLIT_CLASSES];
+#pragma unroll
+  for (int c = 0; c < SPLIT_CLASSES; ++c) pos[c] = cnt_[c][t];
+  for (long i = lo; i < hi; ++i) {
+    const int k = cls[i];
+#pragma unroll
+    for (int c = 0; c < SPLIT_CLASSES; ++c)
+      if (k == c) { ws[SPLIT_HEAD + B * (1 + c) + pos[c]] = (int32_t)i; ++pos[c]; }
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -100,6 +138,11 @@ struct lipmpc_handle {
   int nvar;     // variable slots of the factorisation: G, or 8 (horizons up to 4, register-row instantiations)
   int32_t* sched;       // optional schedule buffer (lipmpc_set_schedule), device memory owned by the caller
   int64_t sched_cap;    // largest batch it holds
+  int32_t* ws;          // optional split-launch workspace (lipmpc_set_workspace), device memory owned by the caller
+  int64_t ws_cap;
+  hipStream_t side[SPLIT_CLASSES - 1];     // the solver bodies of a split launch run side by side (created with the workspace)
+  hipEvent_t fork_ev, join_ev[SPLIT_CLASSES - 1];
+  bool have_streams;
 };
 
 extern "C" {
@@ -153,7 +196,45 @@ int lipmpc_create(const lipmpc_params* p, int device, lipmpc_handle** out) {
   return LIPMPC_OK;
 }
 
-void lipmpc_destroy(lipmpc_handle* h) { free(h); }
+static void drop_streams(lipmpc_handle* h) {
+  if (!h->have_streams) return;
+  (void)hipSetDevice(h->device);
+  for (int i = 0; i < SPLIT_CLASSES - 1; ++i) { (void)hipStreamDestroy(h->side[i]); (void)hipEventDestroy(h->join_ev[i]); }
+  (void)hipEventDestroy(h->fork_ev);
+  h->have_streams = false;
+}
+
+void lipmpc_destroy(lipmpc_handle* h) {
+  if (!h) return;
+  drop_streams(h);
+  free(h);
+}
+
+// does this handle's step run as a split launch when it has a workspace?  (32 lanes per problem, obstacles, presolve on)
+static bool split_capable(const lipmpc_handle* h) {
+  return h->G == 32 && h->nobs_l > 0 && !(h->p.flags & (LIPMPC_FLAG_INTERIOR | LIPMPC_FLAG_NO_PRESOLVE | LIPMPC_FLAG_WARM_START));
+}
+
+int64_t lipmpc_workspace_bytes(const lipmpc_handle* h, int64_t capacity) {
+  if (!h || capacity < 0) return LIPMPC_E_ARG;
+  return split_capable(h) ? (int64_t)sizeof(int32_t) * (SPLIT_HEAD + (1 + SPLIT_CLASSES) * capacity) : 0;
+}
+
+int lipmpc_set_workspace(lipmpc_handle* h, void* workspace, int64_t capacity) {
+  if (!h || capacity < 0 || (workspace && capacity > 0x0fffffff)) return LIPMPC_E_ARG;
+  h->ws = (capacity > 0 && split_capable(h)) ? (int32_t*)workspace : nullptr;
+  h->ws_cap = h->ws ? capacity : 0;
+  if (h->ws && !h->have_streams) {
+    if (hipSetDevice(h->device) != hipSuccess) return LIPMPC_E_HIP;
+    bool ok = hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < SPLIT_CLASSES - 1; ++i)
+      ok = hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&h->join_ev[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { h->ws = nullptr; h->ws_cap = 0; return LIPMPC_E_HIP; }      // (a partial set leaks a few handles at process scope only)
+    h->have_streams = true;
+  }
+  return LIPMPC_OK;
+}
 
 #define LAUNCH(GG, NL, NV)                                                                                     \
   launch_plan_step<GG, NL, NV>(h->k, (long)B, state, goal, first_foot, delta, obs_xy, obs_nv, U, X, theta, omega, obj, \
@@ -172,6 +253,43 @@ static int plan_step_impl(lipmpc_handle* h, int64_t B, const double* state, cons
   if (hipSetDevice(h->device) != hipSuccess) return LIPMPC_E_HIP;
   hipStream_t stream = (hipStream_t)hip_stream;
   int32_t* sched = (h->sched && B <= h->sched_cap) ? h->sched : nullptr;
+  if (h->ws && B <= h->ws_cap && split_capable(h)) {
+    // Split launch: classes -> lists -> one kernel per solver body, side by side.  The rare, long bodies go first on their own
+    // streams (a few waves each, they must not queue behind 2048 short ones); the caller's stream takes the 1-slot body and
+    // waits for the others.
+    constexpr int GPW = WAVE / 32;
+    const unsigned blocks = (unsigned)((B + GPW - 1) / GPW);
+    int32_t* ws = h->ws;
+    int32_t* cost = sched ? sched + SCHED_ORDER + B : nullptr;
+    hipLaunchKernelGGL((classify_kernel<32>), dim3(blocks), dim3(WAVE), 0, stream, h->k, (long)B, state, goal, delta, obs_xy, obs_nv,
+                       bounds, c_eta_in, ws);
+    hipLaunchKernelGGL(split_bin_kernel, dim3(1), dim3(1024), 0, stream, (long)B, ws);
+    const int top = split_class_of((h->p.n_obs_max + 1) / 2);
+#define LIST(NL, CLS, ST)                                                                                                     \
+  launch_solve_list<32, NL, 32>(h->k, (long)B, CLS, ws, state, goal, first_foot, delta, obs_xy, obs_nv, U, X, theta, omega, obj, status, \
+                                iters, (unsigned long long*)active, (unsigned long long*)working, c_eta, diag, bounds, c_eta_in, cost,  \
+                                overflow, ST)
+    static_assert(split_slots(0) == 1 && split_slots(1) == 2 && split_slots(2) == 4 && split_slots(3) == 13 && split_slots(4) == 25,
+                  "the LIST() calls below name the bodies of the classes");
+    if (top >= 1 && hipEventRecord(h->fork_ev, stream) != hipSuccess) return LIPMPC_E_HIP;
+    for (int c = top; c >= 1; --c) {
+      hipStream_t st = h->side[c - 1];
+      if (hipStreamWaitEvent(st, h->fork_ev, 0) != hipSuccess) return LIPMPC_E_HIP;
+      switch (c) {
+        case 4: LIST(25, 4, st); break;
+        case 3: LIST(13, 3, st); break;
+        case 2: LIST(4, 2, st); break;
+        default: LIST(2, 1, st); break;
+      }
+      if (hipEventRecord(h->join_ev[c - 1], st) != hipSuccess) return LIPMPC_E_HIP;
+    }
+    LIST(1, 0, stream);
+    for (int c = top; c >= 1; --c)
+      if (hipStreamWaitEvent(stream, h->join_ev[c - 1], 0) != hipSuccess) return LIPMPC_E_HIP;
+#undef LIST
+    if (sched) hipLaunchKernelGGL(order_by_cost_kernel, dim3(1), dim3(1024), 0, stream, (long)B, sched);
+    return hipGetLastError() == hipSuccess ? LIPMPC_OK : LIPMPC_E_HIP;
+  }
   if (h->G == 16 && h->nvar == 8) {
     switch (h->nobs_l) {
       case 0: LAUNCH(16, 0, 8); break;

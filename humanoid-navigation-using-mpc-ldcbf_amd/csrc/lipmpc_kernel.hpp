@@ -67,6 +67,20 @@ constexpr int WARM_ROWS = 12;                            // register row slots a
 // schedule buffer (int32, lipmpc_set_schedule): [B the order is valid for, -, order[B] (problem at launch position i), cost[B]]
 constexpr int SCHED_VALID = 0, SCHED_ORDER = 2, SCHED_COST_BINS = 128;
 
+// Split launch (lipmpc_set_workspace; 32-lane problems, exact mode with the presolve): a classification pass writes each
+// problem's class = the smallest solver body that holds the obstacles which keep a row after the presolve, a one-workgroup
+// stable counting sort turns the classes into one index list per class, and ONE KERNEL PER BODY solves its list -- each body
+// with its own register allocation (inlined into one kernel the 1 / 2 / 7 / 25-slot bodies of the 32-lane dispatching kernel
+// share one allocation and spill 304 B per lane).  Workspace (int32): [SPLIT_CLASSES counts, padded to 8 | class of problem
+// b: B | list of class c: B each].
+constexpr int SPLIT_CLASSES = 5;
+constexpr int SPLIT_HEAD = 8;
+// row slots per lane of the five bodies: 1, 2, 4 in registers, 13 and 25 streamed through LDS -- every one compiles without
+// scratch on its own (a 5- or 7-slot register body does not: 32 / 208 B per lane)
+__host__ __device__ constexpr int split_slots(int cls) { return cls == 0 ? 1 : cls == 1 ? 2 : cls == 2 ? 4 : cls == 3 ? 13 : 25; }
+__host__ __device__ constexpr int split_class_of(int need) { return need <= 1 ? 0 : need <= 2 ? 1 : need <= 4 ? 2 : need <= 13 ? 3 : 4; }
+constexpr int SPLIT_MAXOBS = 50;       // obstacle slots of the split kernels' front end (every handle's n_obs_max fits)
+
 struct KArgs {
   int N, n_obs, nvert_max, max_iter, flags, fin_rounds;
   int m_tot, words;
@@ -398,13 +412,32 @@ __device__ __forceinline__ void load_bounds(const KArgs& P, const double* __rest
   }
 }
 
+// one problem's inputs, as every lane of its group reads them (the same 64 B: one broadcast transaction)
+__device__ __forceinline__ StepIn load_step_in(const KArgs& P, long pb, bool valid, const double* __restrict__ state,
+                                               const double* __restrict__ goal, const int8_t* __restrict__ first_foot,
+                                               const double* __restrict__ delta_in, const double* __restrict__ bounds,
+                                               const int32_t* __restrict__ overflow_in) {
+  StepIn in;
+  in.valid = valid;
+  in.pb = pb;
+  load_bounds(P, bounds, pb, in);
+  in.p0x = state[pb * 5 + 0]; in.v0x = state[pb * 5 + 1]; in.p0y = state[pb * 5 + 2]; in.v0y = state[pb * 5 + 3];
+  in.th0 = state[pb * 5 + 4];
+  in.gx = goal[pb * 2 + 0]; in.gy = goal[pb * 2 + 1];
+  in.foot0 = first_foot ? (double)first_foot[pb] : 1.0;
+  in.delta = delta_in ? delta_in[pb] : 0.0;
+  in.sensor_overflow = overflow_in && overflow_in[pb] != 0;
+  return in;
+}
+
 // What the front end of a step hands to its solve: headings of the lane's stage, the obstacles' half-spaces COMPACTED in
 // LDS (obs[slot] = eta_x, eta_y, b = eta.c + delta, kfirst = first stage whose row of this obstacle is in the problem;
 // perm[slot] = the obstacle's index in the caller's list, for the canonical row numbers), and the ballast row of the presolve.
 template <int G> struct FrontOut {
   double th_r, th_v, om_a, theta1, omega0, s_own, c_own;   // theta_a, theta_{a+1}, omega_a of the lane's stage; theta_1, omega_0; sin / cos of the lane's angle
   double n_ball, s_ball;                                    // presolve: number of dropped rows, their mean slack at p_0
-  int front_flag;                                           // 1: a constant k = 0 row is violated, 2: degenerate geometry
+  int front_flag;                                           // 1: a constant k = 0 row is violated, 2: degenerate geometry,
+                                                            // 8: more obstacles keep a row than the solver body holds (split launch: cannot happen)
   int n_rel;                                                // obstacle slots in use (group-uniform)
 };
 
@@ -1011,6 +1044,7 @@ __device__ __forceinline__ StepOut step_solve(
   if (front_flag & 2) { status = LIPMPC_STATUS_DEGENERATE; done = true; }
   else if (front_flag & 1) { status = LIPMPC_STATUS_INFEASIBLE; done = true; }
   if (in.sensor_overflow) { status = LIPMPC_STATUS_SENSOR_OVERFLOW; done = true; }     // a truncated obstacle list is not planned against
+  if (front_flag & 8) { status = LIPMPC_STATUS_MAX_ITER; done = true; }                // (never: the body was chosen by this very count)
   if (m_rows == 0.0 && !done) { status = LIPMPC_STATUS_SOLVED; done = true; q = var_on ? gc : 0.0; }
 
   // row-presence masks as 0/1 doubles: an absent row keeps s = 1, z = 0 and is neutralised by four
@@ -1664,28 +1698,78 @@ __global__ __launch_bounds__(WAVE) LIPMPC_OCC void plan_step_kernel(
   static_assert(G == 16 || G == 32, "a problem is one or two DPP rows of one wavefront");
   if (blockDim.x != WAVE) __builtin_trap();          // wave_sync() and every group exchange assume a one-wave workgroup
   const long prob_raw = (long)blockIdx.x * GPW + threadIdx.x / G;
-  StepIn in;
-  in.valid = prob_raw < B;
   // Which problem this group solves: its position in the launch, or -- on a schedule (lipmpc_set_schedule) -- the problem
   // the order left by the previous launch puts there: by descending cost (iterations + finish rounds).  That starts the
   // long solves first, and, as important, puts problems of like cost into the same wave: a wave lasts as long as the
   // slowest of its groups, and the mean of that maximum over four random problems is 12 % above the mean problem.
-  long pb = in.valid ? prob_raw : (B - 1);
+  long pb = prob_raw < B ? prob_raw : (B - 1);
   if (sched && sched[SCHED_VALID] == (int)B) {
     const long r = sched[SCHED_ORDER + pb];
     if (r >= 0 && r < B) pb = r;
   }
-  in.pb = pb;
-  load_bounds(P, bounds, pb, in);
-  // every lane of the group reads the same 64 B: one broadcast transaction
-  in.p0x = state[pb * 5 + 0]; in.v0x = state[pb * 5 + 1]; in.p0y = state[pb * 5 + 2]; in.v0y = state[pb * 5 + 3];
-  in.th0 = state[pb * 5 + 4];
-  in.gx = goal[pb * 2 + 0]; in.gy = goal[pb * 2 + 1];
-  in.foot0 = (double)first_foot[pb];
-  in.delta = delta_in ? delta_in[pb] : 0.0;
-  in.sensor_overflow = overflow_in && overflow_in[pb] != 0;
+  const StepIn in = load_step_in(P, pb, prob_raw < B, state, goal, first_foot, delta_in, bounds, overflow_in);
   step_body<G, NOBS_L, NVAR, DISPATCH>(P, in, obs_xy, obs_nv, U, X, theta_out, omega_out, obj_out, status_out, iters_out, active_out,
                                        working_out, c_eta, diag, c_eta_in, nullptr, sched ? sched + SCHED_ORDER + B : nullptr);
+}
+
+// ------------------------------------------------------------------------------------------
+// kernels 1b: the split launch of one MPC step (see SPLIT_CLASSES above): classify -> bin -> one kernel per solver body
+// ------------------------------------------------------------------------------------------
+// The class of every problem: the front end alone (0.7 % of a step at N = 16 / 50 obstacles), one group of G lanes per
+// problem exactly as the solving kernels run it -- the same code on the same inputs, hence the same count.
+template <int G>
+__global__ __launch_bounds__(WAVE) void classify_kernel(
+    KArgs P, long B, const double* __restrict__ state, const double* __restrict__ goal, const double* __restrict__ delta_in,
+    const double* __restrict__ obs_xy, const int32_t* __restrict__ obs_nv, const double* __restrict__ bounds,
+    const double* __restrict__ c_eta_in, int32_t* __restrict__ ws) {
+  constexpr int GPW = WAVE / G;
+  constexpr int RING_CAP = (G == 16) ? 64 : 256;
+  if (blockDim.x != WAVE) __builtin_trap();
+  __shared__ double lds_ring[GPW][RING_CAP][2];
+  __shared__ double lds_obs[GPW][SPLIT_MAXOBS][4];
+  __shared__ int lds_perm[GPW][SPLIT_MAXOBS];
+  __shared__ int lds_flag[GPW];
+  const int grp = threadIdx.x / G;
+  const long prob_raw = (long)blockIdx.x * GPW + grp;
+  const long pb = prob_raw < B ? prob_raw : (B - 1);
+  const StepIn in = load_step_in(P, pb, prob_raw < B, state, goal, nullptr, delta_in, bounds, nullptr);
+  const FrontOut<G> F = front_end<G, SPLIT_MAXOBS>(P, in, obs_xy, obs_nv, nullptr, nullptr, nullptr, c_eta_in, true, lds_ring[grp],
+                                                   lds_obs[grp], lds_perm[grp], &lds_flag[grp]);
+  if (in.valid && (threadIdx.x & (G - 1)) == 0) ws[SPLIT_HEAD + pb] = split_class_of((F.n_rel + 1) >> 1);
+}
+
+// One solver body over its class's list: the step kernel with NL row slots per lane and nothing else in its register
+// allocation.  Launched with the grid of the whole batch (the counts live on the device); the blocks past the list's end leave
+// at once.
+template <int G, int NL, int NVAR>
+__global__ __launch_bounds__(WAVE) void solve_list_kernel(
+    KArgs P, long B, int cls, const int32_t* __restrict__ ws, const double* __restrict__ state, const double* __restrict__ goal,
+    const int8_t* __restrict__ first_foot, const double* __restrict__ delta_in,
+    const double* __restrict__ obs_xy, const int32_t* __restrict__ obs_nv,
+    double* __restrict__ U, double* __restrict__ X, double* __restrict__ theta_out,
+    double* __restrict__ omega_out, double* __restrict__ obj_out, int32_t* __restrict__ status_out,
+    int32_t* __restrict__ iters_out, unsigned long long* __restrict__ active_out,
+    unsigned long long* __restrict__ working_out, double* __restrict__ c_eta,
+    double* __restrict__ diag, const double* __restrict__ bounds, const double* __restrict__ c_eta_in,
+    int32_t* __restrict__ cost_out, const int32_t* __restrict__ overflow_in) {
+  constexpr int GPW = WAVE / G;
+  constexpr int RING_CAP = (G == 16) ? 64 : 256;
+  if (blockDim.x != WAVE) __builtin_trap();
+  const int count = ws[cls];
+  if ((long)blockIdx.x * GPW >= count) return;                    // (wave-uniform)
+  __shared__ double lds_ring[GPW][RING_CAP][2];
+  __shared__ double lds_obs[GPW][SPLIT_MAXOBS][4];
+  __shared__ int lds_perm[GPW][SPLIT_MAXOBS];
+  __shared__ int lds_flag[GPW];
+  const int grp = threadIdx.x / G;
+  const long idx = (long)blockIdx.x * GPW + grp;
+  const long pb = ws[SPLIT_HEAD + B * (1 + cls) + (idx < count ? idx : count - 1)];
+  const StepIn in = load_step_in(P, pb, idx < count, state, goal, first_foot, delta_in, bounds, overflow_in);
+  FrontOut<G> F = front_end<G, SPLIT_MAXOBS>(P, in, obs_xy, obs_nv, theta_out, omega_out, c_eta, c_eta_in, true, lds_ring[grp],
+                                             lds_obs[grp], lds_perm[grp], &lds_flag[grp]);
+  if (F.n_rel > 2 * NL) F.front_flag |= 8;
+  step_solve<G, NL, NVAR, false>(P, in, F, lds_obs[grp], lds_perm[grp], U, X, obj_out, status_out, iters_out, active_out, working_out,
+                                 diag, nullptr, cost_out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1784,5 +1868,12 @@ void launch_rollout(const KArgs& k, long B, int k_max, int mpc_step, double stop
                     const double* goal, const int8_t* first_foot, const double* delta, const double* obs_xy,
                     const int32_t* obs_nv, double* X_pred, double* U_pred, int32_t* n_steps, int32_t* last_status,
                     int32_t* total_iters, const double* bounds, hipStream_t stream);
+// one solver body of the split launch over its class's list (32 lanes per problem; defined in lipmpc_inst.hip)
+template <int G, int NL, int NVAR>
+void launch_solve_list(const KArgs& k, long B, int cls, const int32_t* ws, const double* state, const double* goal,
+                       const int8_t* first_foot, const double* delta, const double* obs_xy, const int32_t* obs_nv, double* U,
+                       double* X, double* theta, double* omega, double* obj, int32_t* status, int32_t* iters,
+                       unsigned long long* active, unsigned long long* working, double* c_eta, double* diag, const double* bounds,
+                       const double* c_eta_in, int32_t* cost_out, const int32_t* overflow_in, hipStream_t stream);
 
 }  // namespace lipmpc_dev

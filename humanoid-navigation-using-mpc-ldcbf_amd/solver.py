@@ -81,6 +81,25 @@ class BatchedLipMpc:
         self._h = C.c_void_p()
         cp = params.to_c()
         _lib.check(self.lib.lipmpc_create(C.byref(cp), self.device_index, C.byref(self._h)), "lipmpc_create")
+        # split launch (one kernel per solver body): the library says whether this handle's steps can use it
+        self.auto_workspace = True
+        self._ws, self._ws_cap = None, 0
+        self._split_capable = int(self.lib.lipmpc_workspace_bytes(self._h, 1)) > 0
+
+    def set_workspace(self, capacity):
+        """Split launch of this handle's step solves (lipmpc_set_workspace): for 32-lane problems (N > 8) in the exact mode
+        the step runs as classification -> index lists -> one kernel per solver body (each with its own register
+        allocation), bit-identical results.  The handle sets one up by itself for the batch sizes it sees
+        (``auto_workspace``); 0 = back to the single dispatching kernel."""
+        capacity = int(capacity)
+        nbytes = int(self.lib.lipmpc_workspace_bytes(self._h, capacity)) if capacity > 0 else 0
+        self._ws = torch.empty((nbytes // 4,), dtype=torch.int32, device=self.device) if nbytes > 0 else None
+        self._ws_cap = capacity if self._ws is not None else 0
+        _lib.check(self.lib.lipmpc_set_workspace(self._h, _ptr(self._ws), self._ws_cap), "lipmpc_set_workspace")
+
+    def _ensure_workspace(self, B):
+        if self.auto_workspace and B > getattr(self, "_ws_cap", 0) and self._split_capable:
+            self.set_workspace(B)
 
     def set_schedule(self, capacity):
         """Launch order for this handle's step solves (lipmpc_set_schedule): every plan_step_batch / plan_step_batch_c_eta of
@@ -153,6 +172,7 @@ class BatchedLipMpc:
             out = self.alloc_outputs(B, with_c_eta, with_diag, with_working)
         else:
             self._check_outputs(out, B)
+        self._ensure_workspace(B)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = self.lib.lipmpc_plan_step_batch(
             self._h, B, _ptr(state), _ptr(goal), _ptr(first_foot), _ptr(delta), _ptr(obs_xy), _ptr(obs_nv),
@@ -181,6 +201,7 @@ class BatchedLipMpc:
             out = self.alloc_outputs(B, False, with_diag, with_working)
         else:
             self._check_outputs(out, B)
+        self._ensure_workspace(B)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         rc = self.lib.lipmpc_plan_step_batch_c_eta(
             self._h, B, _ptr(state), _ptr(goal), _ptr(first_foot), _ptr(delta), _ptr(c_eta_in), _ptr(overflow),

@@ -164,6 +164,21 @@ int lipmpc_plan_step_batch(lipmpc_handle* h, int64_t B,
 int lipmpc_set_schedule(lipmpc_handle* h, int32_t* schedule, int64_t capacity);
 int64_t lipmpc_schedule_words(int64_t B);
 
+/* Optional workspace for the SPLIT LAUNCH of a handle's step solves.  For 32-lane problems (N > 8) in the exact mode the
+ * step kernel holds the solver bodies of 1, 2, 7 and the handle's LDCBF row slots per lane next to each other and a wave
+ * picks the smallest that fits its problems after the presolve -- one register allocation for all of them, which spills
+ * (304 B of scratch per lane at N = 16 / 50 obstacles).  With a workspace the step runs as: one classification pass (the
+ * front end alone: which body each problem needs), a one-workgroup stable counting sort into one index list per body, and ONE
+ * KERNEL PER BODY over its list, the kernels side by side on streams the handle owns (fork / join by events on the caller's
+ * stream, so the call stays asynchronous and stream-ordered, and can be captured in a graph).  Results are bit-identical
+ * to the single-kernel launch; problems of one class share waves.  Ignored (single kernel) for N <= 8, for the flags that
+ * keep every row, and for batches larger than the workspace was sized for.  While it is set, the order of
+ * lipmpc_set_schedule is not applied (the costs are still left).
+ * `workspace`: device buffer of lipmpc_workspace_bytes(h, capacity) bytes, contents arbitrary, owned by the caller, alive
+ * until unset (NULL) or the handle is destroyed; launches on it must be stream-ordered. */
+int64_t lipmpc_workspace_bytes(const lipmpc_handle* h, int64_t capacity);
+int lipmpc_set_workspace(lipmpc_handle* h, void* workspace, int64_t capacity);
+
 /* The same step with the LDCBF half-spaces GIVEN instead of derived from obstacle rings: the reference's subclass
  * hooks HumanoidMPC._get_list_c_and_eta(x_k, y_k) -> (list_c, list_eta) (HumanoidMpc.py:296-319; overridden by
  * HumanoidMPCUnknownEnvironment.py:30-68) and _compute_single_lcbf(x, eta, c) (HumanoidMpc.py:252-261; overridden by

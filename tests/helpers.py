@@ -126,6 +126,30 @@ def convex_ring(pts):
     return np.array(lo[:-1] + up[:-1])
 
 
+def crowded_batch(N, n_obs, B, seed):
+    """Robots in the middle of a ring of small obstacles -- 0 to n_obs of them within reach of the horizon, a different number
+    per robot, anywhere in the obstacle list -- so that after the presolve the problems of one batch need every solver body
+    (1, 2, 4 / 7, 13, 25 row slots per lane).  Returns state [B,5], goal [B,2], foot [B], obs_xy [B,n_obs,5,2], obs_nv."""
+    rng = np.random.default_rng(seed)
+    xy = np.zeros((B, n_obs, 5, 2)); nv = np.zeros((B, n_obs), np.int32)
+    st = np.zeros((B, 5)); st[:, 0] = rng.uniform(2, 8, B); st[:, 2] = rng.uniform(2, 8, B); st[:, 4] = rng.uniform(-3, 3, B)
+    st[:, 3] = np.where(rng.random(B) < 0.5, 0.2, -0.2)
+    foot = np.where(st[:, 3] > 0, 1, -1).astype(np.int8)
+    for b in range(B):
+        near = rng.integers(0, n_obs + 1)                       # obstacles within reach of the horizon
+        for j in range(n_obs):
+            rad = rng.uniform(0.35, 0.18 * N + 0.2) if j < near else rng.uniform(0.18 * N + 1.0, 0.18 * N + 6.0)
+            ang = rng.uniform(0, 2 * np.pi)
+            c = np.array([st[b, 0] + rad * np.cos(ang), st[b, 2] + rad * np.sin(ang)])
+            a0 = rng.uniform(0, 2 * np.pi)
+            xy[b, j, :3] = c + 0.08 * np.array([[np.cos(a0 + t), np.sin(a0 + t)] for t in (0.0, 2.1, 4.2)])     # CCW triangle
+            nv[b, j] = 3
+        perm = rng.permutation(n_obs)                           # the near ones anywhere in the list
+        xy[b], nv[b] = xy[b, perm], nv[b, perm]
+    goal = st[:, [0, 2]] + rng.uniform(-6, 6, (B, 2))
+    return st, goal, foot, xy, nv
+
+
 def closed_loop_problems(N, n_obs, ntraj, steps, seed=0, delta=0.0, fields=None, goal=(10.0, 10.0)):
     """Yield (state, goal, s0, obstacles, delta) along oracle closed-loop walks from the origin
     (interior iterates advance the loop), i.e. reachable walking states."""

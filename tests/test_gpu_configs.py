@@ -339,3 +339,69 @@ def test_config4_reference_generated_fields(golden_dir):
     assert np.array_equal(g["c_eta"], ref["c_eta"])
     _compare_with_oracle("config 4 (reference fields)", P, g, ref, min_compared=MIN_ACTIVE_COMPARED_CFG4, iters_bars=(0.85, 0.97), max_split=0.004,
                          min_status_equal=0.99)
+
+
+@pytest.mark.parametrize("N,n_obs", [(16, 50), (12, 9), (16, 30)])
+def test_split_launch_against_the_single_kernel_and_the_oracle(N, n_obs):
+    """lipmpc_set_workspace: 32-lane problems in the exact mode run as classification -> one index list per solver body ->
+    ONE KERNEL PER BODY (1, 2, 4 register / 13, 25 streamed row slots per lane, side by side on the handle's streams) instead of
+    the one kernel that holds the bodies next to each other and spills.  A problem may run in another body than in the single
+    kernel (there a wave takes the body of its neediest problem; the bodies differ in summation order), so the two launches
+    agree as two solvers do: same statuses, iteration counts, footsteps to 1e-7, identical active sets; the split launch
+    itself is deterministic (launch after launch bit-identical, the lists a stable sort) and is held to the C oracle like any
+    other path.  Crowded robots: their problems need every body.  Also: the half-spaces given (c_eta entry point), and a batch
+    beyond the workspace (falls back to the single kernel)."""
+    import c_oracle
+    from helpers import crowded_batch
+    B = 1500
+    st, goal, foot, xy, nv = crowded_batch(N, n_obs, B, seed=3 * N + n_obs)
+    args = (_dev(st, torch.float64), _dev(goal, torch.float64), _dev(foot, torch.int8), _dev(xy, torch.float64), _dev(nv, torch.int32), None)
+    P = lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5)
+    one = lipmpc.BatchedLipMpc(P)
+    one.auto_workspace = False
+    ref = one.plan_step_batch(*args, with_diag=True, with_working=True, with_c_eta=True)
+    sv = lipmpc.BatchedLipMpc(P)
+    assert sv._split_capable
+    keys = ("U", "X", "obj", "theta", "omega", "status", "iters", "active", "working", "diag", "c_eta")
+    eq = lambda a, b: torch.equal(torch.nan_to_num(a.double(), nan=7.0), torch.nan_to_num(b.double(), nan=7.0))
+    first = sv.plan_step_batch(*args, with_diag=True, with_working=True, with_c_eta=True)
+    torch.cuda.synchronize()
+    assert sv._ws is not None and sv._ws_cap == B
+    again = sv.plan_step_batch(*args, with_diag=True, with_working=True, with_c_eta=True)
+    torch.cuda.synchronize()
+    for k in keys:
+        assert eq(first[k], again[k]), k                    # deterministic
+    for k in ("theta", "omega", "c_eta", "status"):
+        assert eq(first[k], ref[k]), k                      # the shared front end: bit-identical
+    g = {k: v.cpu().numpy() for k, v in first.items()}
+    r1 = {k: v.cpu().numpy() for k, v in ref.items()}
+    ok = g["status"] == 0
+    assert np.max(np.abs(g["U"][ok] - r1["U"][ok])) < 1e-7 and np.mean(g["iters"] == r1["iters"]) > 0.97
+    info, _ = compare_active_sets(ok, g, r1)
+    assert_active_sets(f"split vs single N={N} n_obs={n_obs}", info, 0.97)
+    oracle = c_oracle.plan_step_batch(P, st, goal, foot, xy, nv, None, n_threads=16)
+    assert np.array_equal(g["status"], oracle["status"])
+    assert np.max(np.abs(g["U"][ok] - oracle["U"][ok])) < 1e-6
+    info, _ = compare_active_sets(ok, g, oracle)
+    print("split launch vs C oracle", N, n_obs, info)
+    assert_active_sets(f"split vs oracle N={N} n_obs={n_obs}", info, 0.95)
+    ws = sv._ws.cpu().numpy()
+    counts, cls = ws[:5], ws[8:8 + B]
+    assert counts.sum() == B and np.array_equal(np.bincount(cls, minlength=5), counts)
+    for c in range(5):                                      # the lists: each class's problems in index order (stable sort)
+        assert np.array_equal(ws[8 + B * (1 + c): 8 + B * (1 + c) + counts[c]], np.where(cls == c)[0])
+    assert (counts > 0).sum() >= (4 if n_obs >= 30 else 3), counts          # the crowded robots really spread over the bodies
+    # given half-spaces through the same split launch: the same bits as from the rings
+    b = sv.plan_step_batch_c_eta(args[0], args[1], args[2], first["c_eta"].contiguous(), None, with_diag=True)
+    torch.cuda.synchronize()
+    for k in ("U", "status", "iters", "active", "diag"):
+        assert eq(first[k], b[k]), k
+    # a batch larger than the workspace: the single kernel (auto growth off)
+    sv.auto_workspace = False
+    sv.set_workspace(100)
+    got = sv.plan_step_batch(*args)
+    torch.cuda.synchronize()
+    assert eq(got["U"], ref["U"]) and eq(got["iters"], ref["iters"])
+    # handles that never split: 16 lanes per problem, or the modes that keep every row
+    assert not lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=8, n_obs_max=10, v_max=5))._split_capable
+    assert not lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=16, n_obs_max=10, v_max=5, flags=lipmpc.FLAG_INTERIOR))._split_capable

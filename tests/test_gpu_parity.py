@@ -761,24 +761,9 @@ def test_crowded_robots_reach_every_solver_body(N, n_obs):
     per robot -- send waves to every body of the dispatching kernel; statuses, footsteps and decisive active sets against the
     C oracle, and bit-identical answers from the kernel that keeps every row in the handle's own body."""
     import c_oracle
-    rng = np.random.default_rng(7 * N + n_obs)
+    from helpers import crowded_batch
     B = 256
-    xy = np.zeros((B, n_obs, 5, 2)); nv = np.zeros((B, n_obs), np.int32)
-    st = np.zeros((B, 5)); st[:, 0] = rng.uniform(2, 8, B); st[:, 2] = rng.uniform(2, 8, B); st[:, 4] = rng.uniform(-3, 3, B)
-    st[:, 3] = np.where(rng.random(B) < 0.5, 0.2, -0.2)
-    foot = np.where(st[:, 3] > 0, 1, -1).astype(np.int8)
-    for b in range(B):
-        near = rng.integers(0, n_obs + 1)                       # obstacles within reach of the horizon
-        for j in range(n_obs):
-            rad = rng.uniform(0.35, 0.18 * N + 0.2) if j < near else rng.uniform(0.18 * N + 1.0, 0.18 * N + 6.0)
-            ang = rng.uniform(0, 2 * np.pi)
-            c = np.array([st[b, 0] + rad * np.cos(ang), st[b, 2] + rad * np.sin(ang)])
-            a0 = rng.uniform(0, 2 * np.pi)
-            xy[b, j, :3] = c + 0.08 * np.array([[np.cos(a0 + t), np.sin(a0 + t)] for t in (0.0, 2.1, 4.2)])     # CCW triangle
-            nv[b, j] = 3
-        perm = rng.permutation(n_obs)                           # the near ones anywhere in the list
-        xy[b], nv[b] = xy[b, perm], nv[b, perm]
-    goal = st[:, [0, 2]] + rng.uniform(-6, 6, (B, 2))
+    st, goal, foot, xy, nv = crowded_batch(N, n_obs, B, seed=7 * N + n_obs)
     dev = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device="cuda")
     args = (dev(st, torch.float64), dev(goal, torch.float64), dev(foot, torch.int8), dev(xy, torch.float64), dev(nv, torch.int32), None)
     P = lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5)
