@@ -296,14 +296,35 @@ __device__ __forceinline__ double zero_unless(bool c, double x) {
 // compiler from moving accesses across the point -- a workgroup-scope fence, no s_barrier.  Unlike __syncthreads()
 // this is well defined inside the divergent regions it is used in (groups of a wave leave the solver loops
 // independently).
-// Dev instrumentation (tools/phase_cycles.py, -DLIPMPC_PHASE_TIMING variant only): shader-clock cycles per section of the step,
-// summed over a wave's lifetime, written to diag[pb * 16 + k] (the tool hands in a [B,16] buffer).  Sections: 0 iteration head
-// (statistics, streamed pass A), 1 reciprocals + K, 2 factorisation, 3 predictor rhs + solve, 4 predictor rows / ratio / mu_aff,
-// 5 corrector rhs + solve, 6 corrector rows / ratio / update, 7 finish: K + factorisation, 8 finish: equality solve,
-// 9 finish: ratio test / exchange / certificate, 10 front end, 11 outputs.
+// Dev instrumentation (tools/phase_cycles.py, -DLIPMPC_PHASE_TIMING variant only; such a build reports another lipmpc_version()
+// and is refused by the product loader): time per section of the step, accounted PER WAVE -- a workgroup is one wave, the
+// accumulators live in LDS and every marker is booked once per wave pass by the first lane that is active there, whatever
+// subset of the wave's groups is still running (per-lane accumulators, as rounds 2-3 had them, charge a finished group's
+// waiting time to its next marker).  Constant 100 MHz clock (wall_clock64).  Record of a wave, written to
+// diag[(first problem of the wave) * 32 + k]: k < 12 ns per section, 12 + k the part of it spent with ONE group of the wave
+// alive (the tail inside the wave), 24 wave lifetime ns, 25 wave lifetime in shader-clock ticks, 26 / 27 iterations / rounds
+// of the wave's slowest group.  Sections: 0 iteration head (statistics, streamed pass A), 1 reciprocals + K, 2 factorisation,
+// 3 predictor rhs + solve, 4 predictor rows / ratio / mu_aff, 5 corrector rhs + solve, 6 corrector rows / ratio / update,
+// 7 finish: K + factorisation, 8 finish: equality solve, 9 finish: ratio test / exchange / certificate, 10 front end,
+// 11 outputs.
 #ifdef LIPMPC_PHASE_TIMING
-#define PH_DECL long long ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long ph_t = __builtin_readcyclecounter();
-#define PH(k) { const long long n_ = __builtin_readcyclecounter(); ph_acc[k] += n_ - ph_t; ph_t = n_; }
+constexpr int PH_WORDS = 32;
+__device__ __forceinline__ void ph_mark(unsigned long long* acc, int k, int G) {
+  const unsigned long long now = wall_clock64();
+  const unsigned long long live = __ballot(1);
+  if ((int)threadIdx.x == __ffsll((long long)live) - 1) {
+    const unsigned long long dt = now - acc[31];
+    acc[k] += dt;
+    if (__popcll(live) <= G) acc[12 + k] += dt;
+    acc[31] = now;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+#define PH_DECL __shared__ unsigned long long ph_acc_[PH_WORDS];                                                   \
+  if (threadIdx.x == 0) { for (int k_ = 0; k_ < PH_WORDS; ++k_) ph_acc_[k_] = 0ull; ph_acc_[31] = in.t_start_wall; }     \
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+#define PH(k) ph_mark(ph_acc_, k, G);
 #else
 #define PH_DECL
 #define PH(k)
@@ -388,6 +409,9 @@ struct StepIn {
   long pb;          // problem index (obstacle arrays, step outputs)
   bool valid;       // false: padding group of the last workgroup (computes, never writes)
   bool sensor_overflow = false;   // the producer of the given half-spaces dropped obstacles (lipmpc_lidar_c_eta_batch: overflow): not solved
+#ifdef LIPMPC_PHASE_TIMING
+  unsigned long long t_start_wall = 0ull, t_start_ticks = 0ull;      // kernel entry (dev instrumentation)
+#endif
 };
 struct StepOut {
   int status, iters;
@@ -418,6 +442,9 @@ __device__ __forceinline__ StepIn load_step_in(const KArgs& P, long pb, bool val
                                                const double* __restrict__ delta_in, const double* __restrict__ bounds,
                                                const int32_t* __restrict__ overflow_in) {
   StepIn in;
+#ifdef LIPMPC_PHASE_TIMING
+  in.t_start_wall = wall_clock64(); in.t_start_ticks = (unsigned long long)__builtin_readcyclecounter();
+#endif
   in.valid = valid;
   in.pb = pb;
   load_bounds(P, bounds, pb, in);
@@ -443,7 +470,7 @@ template <int G> struct FrontOut {
 
 // Front end of a step (shared by every solver body of a kernel): theta / omega, closest point and normal per obstacle,
 // presolve, compaction of the obstacles that still have a row into the leading slots.
-template <int G, int MAXOBS>
+template <int G, int MAXOBS, bool PREFETCH = true>
 __device__ __forceinline__ FrontOut<G> front_end(
     const KArgs& P, const StepIn& in, const double* __restrict__ obs_xy, const int32_t* __restrict__ obs_nv,
     double* __restrict__ theta_out, double* __restrict__ omega_out, double* __restrict__ c_eta,
@@ -460,6 +487,40 @@ __device__ __forceinline__ FrontOut<G> front_end(
   const int c = lane & 1;              // coordinate
   const double p0x = in.p0x, p0y = in.p0y, th0 = in.th0;
   const double gx = in.gx, gy = in.gy, delta = in.delta;
+
+  // ---- the obstacle data of the problem: every global load issued NOW, consumed after the heading arithmetic ------------
+  // (a group's rings, vertex counts / given half-spaces depend on the problem index alone; fetched where they are used they
+  // were two further memory round trips in a row behind the state's -- 2 us of a wave's 8 us fixed cost at one wave per SIMD)
+  constexpr int RING_REGS = (2 * RING_CAP + G - 1) / G;      // doubles of the staged rings per lane
+  constexpr int SWEEPS = (MAXOBS + G - 1) / G;               // obstacle sweeps of the group
+  const bool staged = MAXOBS > 0 && !c_eta_in && P.n_obs * P.nvert_max <= RING_CAP;     // wave-uniform
+  // (PREFETCH = false: the closed-loop kernel, whose register file is full -- it fetches where it stores, as before)
+  double ring_pre[MAXOBS > 0 ? RING_REGS : 1];
+  int nv_pre[SWEEPS > 0 ? SWEEPS : 1];
+  double ce_pre[SWEEPS > 0 ? SWEEPS : 1][4];
+  auto fetch_obstacles = [&]() {
+    if (staged) {
+      const double* src = obs_xy + pb * (long)P.n_obs * P.nvert_max * 2;
+      const int total = P.n_obs * P.nvert_max * 2;
+#pragma unroll
+      for (int r = 0; r < RING_REGS; ++r) { const int v = lane + r * G; ring_pre[r] = (v < total) ? src[v] : 0.0; }
+    }
+#pragma unroll
+    for (int sw = 0; sw < SWEEPS; ++sw) {
+      const int j = sw * G + lane;
+      nv_pre[sw] = 0;
+      ce_pre[sw][0] = ce_pre[sw][1] = ce_pre[sw][2] = ce_pre[sw][3] = 0.0;
+      if (j < P.n_obs) {
+        if (c_eta_in) {
+          const double* ce = c_eta_in + (pb * P.n_obs + j) * 4;
+          ce_pre[sw][0] = ce[0]; ce_pre[sw][1] = ce[1]; ce_pre[sw][2] = ce[2]; ce_pre[sw][3] = ce[3];
+        } else {
+          nv_pre[sw] = obs_nv[pb * P.n_obs + j];
+        }
+      }
+    }
+  };
+  if constexpr (MAXOBS > 0 && PREFETCH) fetch_obstacles();
 
   // ---- theta / omega (HumanoidMpc.py:137-160) -------------------------------------------------
   const double psi = atan2(gy - p0y, gx - p0x);
@@ -495,11 +556,18 @@ __device__ __forceinline__ FrontOut<G> front_end(
   const bool compact = cold;
   double nd_l = 0.0, ss_l = 0.0;          // this lane's share of n_d and of the dropped rows' slack sum
   if (lane == 0) *lds_flag_g = 0;
-  const bool staged = MAXOBS > 0 && !c_eta_in && P.n_obs * P.nvert_max <= RING_CAP;     // wave-uniform
-  if (staged) {
-    const double* src = obs_xy + pb * (long)P.n_obs * P.nvert_max * 2;
-    double* dst = &lds_ring[0][0];
-    for (int v = lane; v < P.n_obs * P.nvert_max * 2; v += G) dst[v] = src[v];
+  if constexpr (MAXOBS > 0) {
+    if (staged) {
+      double* dst = &lds_ring[0][0];
+      const int total = P.n_obs * P.nvert_max * 2;
+      if constexpr (PREFETCH) {
+#pragma unroll
+        for (int r = 0; r < RING_REGS; ++r) { const int v = lane + r * G; if (v < total) dst[v] = ring_pre[r]; }
+      } else {
+        const double* src = obs_xy + pb * (long)P.n_obs * P.nvert_max * 2;
+        for (int v = lane; v < total; v += G) dst[v] = src[v];
+      }
+    }
   }
   if (MAXOBS > 0) {
     for (int j = lane; j < MAXOBS; j += G) {       // every slot starts empty (kfirst = +inf), harmless values
@@ -510,7 +578,9 @@ __device__ __forceinline__ FrontOut<G> front_end(
   wave_sync();
   int n_rel = 0;
   if (MAXOBS > 0) {
-    for (int j0 = 0; j0 < MAXOBS; j0 += G) {       // (uniform trip count: the compaction is a ballot over the wave)
+#pragma unroll
+    for (int sw = 0; sw < SWEEPS; ++sw) {          // (uniform trip count: the compaction is a ballot over the wave)
+      const int j0 = sw * G;
       const int j = j0 + lane;
       bool keep = false;                           // this obstacle takes a slot
       double cx = 0, cy = 0, ex = 0, ey = 0, bb = 0, h0 = INFINITY, kfirst = INFINITY;
@@ -518,12 +588,12 @@ __device__ __forceinline__ FrontOut<G> front_end(
         const long oidx = pb * P.n_obs + j;
         bool there, degen = false;
         if (c_eta_in) {      // caller-supplied half-spaces (the reference's _get_list_c_and_eta hook): eta = (0,0) = empty slot, NaN = degenerate
-          const double* ce = c_eta_in + oidx * 4;
-          cx = ce[0]; cy = ce[1]; ex = ce[2]; ey = ce[3];
+          if constexpr (PREFETCH) { cx = ce_pre[sw][0]; cy = ce_pre[sw][1]; ex = ce_pre[sw][2]; ey = ce_pre[sw][3]; }
+          else { const double* ce = c_eta_in + oidx * 4; cx = ce[0]; cy = ce[1]; ex = ce[2]; ey = ce[3]; }
           there = (ex != 0.0) || (ey != 0.0);
           degen = (ex != ex) || (ey != ey);       // NaN normal: the producer met degenerate geometry (lipmpc_lidar_c_eta_batch)
         } else {
-          const int nv = obs_nv[oidx];
+          const int nv = PREFETCH ? nv_pre[sw] : obs_nv[oidx];
           there = nv > 0;
           if (there) {
             const ClosestPoint cp = staged ? closest_point_impl(&lds_ring[j * P.nvert_max][0], nv, p0x, p0y)
@@ -1614,9 +1684,18 @@ __device__ __forceinline__ StepOut step_solve(
   }
   PH(11)
 #ifdef LIPMPC_PHASE_TIMING
-  if (valid && diag && lane == 0) {
-    for (int k = 0; k < 12; ++k) diag[pb * 16 + k] = (double)ph_acc[k];
-    diag[pb * 16 + 12] = iters; diag[pb * 16 + 13] = diag_rounds;
+  {
+    const int it_w = max(iters, max(__shfl_xor(iters, 16), max(__shfl_xor(iters, 32), __shfl_xor(iters, 48))));
+    const int rd = (int)diag_rounds;
+    const int rd_w = max(rd, max(__shfl_xor(rd, 16), max(__shfl_xor(rd, 32), __shfl_xor(rd, 48))));
+    const long slot = __builtin_amdgcn_readfirstlane((int)pb);
+    if (diag && threadIdx.x == 0) {
+      double* o = diag + slot * PH_WORDS;
+      for (int k = 0; k < 24; ++k) o[k] = 10.0 * (double)ph_acc_[k];                   // 100 MHz ticks -> ns
+      o[24] = 10.0 * (double)(wall_clock64() - in.t_start_wall);
+      o[25] = (double)((unsigned long long)__builtin_readcyclecounter() - in.t_start_ticks);
+      o[26] = it_w; o[27] = rd_w; o[28] = 1.0;
+    }
   }
 #endif
   StepOut r;
@@ -1653,8 +1732,8 @@ __device__ __forceinline__ StepOut step_body(
   __shared__ int lds_need[GPW];
   const int grp = threadIdx.x / G;
   const bool cold = (warm == nullptr) || (warm->lds == nullptr);
-  const FrontOut<G> F = front_end<G, MAXOBS>(P, in, obs_xy, obs_nv, theta_out, omega_out, c_eta, c_eta_in, cold, lds_ring[grp],
-                                             lds_obs[grp], lds_perm[grp], &lds_flag[grp]);
+  const FrontOut<G> F = front_end<G, MAXOBS, !LEAN>(P, in, obs_xy, obs_nv, theta_out, omega_out, c_eta, c_eta_in, cold, lds_ring[grp],
+                                                    lds_obs[grp], lds_perm[grp], &lds_flag[grp]);
 #define LIPMPC_SOLVE(NL) step_solve<G, NL, NVAR, LEAN>(P, in, F, lds_obs[grp], lds_perm[grp], U, X, obj_out, status_out, iters_out, active_out, working_out, diag, warm, cost_out)
   if constexpr (DISPATCH && NOBS_L > 1) {
     if ((threadIdx.x & (G - 1)) == 0) lds_need[grp] = (F.n_rel + 1) >> 1;      // row slots per lane this group's obstacles need
