@@ -89,14 +89,16 @@ def launch_ranks(cmd, argv):
     return r.returncode if r.returncode != 0 else (0 if len(lines) == 1 else 3)
 
 
-def make_inputs(lipmpc, synth, B, N, n_obs, lo, rank, dev, local_rank, n_fields=None, walk_steps=30):
+def make_inputs(lipmpc, synth, B, N, n_obs, lo, rank, dev, local_rank, n_fields=None, walk_steps=30, fields=None):
     """The benchmark batch: generate_obstacles-distributed fields (seed = first global index of the shard),
     delta = 0 and 0.3 variants (0.3 only where the start keeps that clearance), states = live robots of an on-device
-    closed-loop warm-up of 0..walk_steps MPC steps.  n_fields < B: fields reused by several robots (different states)."""
+    closed-loop warm-up of 0..walk_steps MPC steps.  n_fields < B: fields reused by several robots (different states).
+    fields = (xy, nv): these fields (the committed output of the reference's own generator) instead of generated ones."""
     hi = 9.5 if N <= 8 else 15.5
     goal_xy = (10.0, 10.0) if N <= 8 else (16.0, 16.0)
     nf = n_fields or B
-    xy, nv = synth.synthetic_fields(nf, n_obs, 0.5, hi, (0.0, 0.0), goal_xy, seed=1234 + lo)
+    xy, nv = fields if fields is not None else synth.synthetic_fields(nf, n_obs, 0.5, hi, (0.0, 0.0), goal_xy, seed=1234 + lo)
+    nf = len(nv)
     if nf < B:
         rep = -(-B // nf)
         xy, nv = np.tile(xy, (rep, 1, 1, 1))[:B], np.tile(nv, (rep, 1))[:B]
@@ -155,6 +157,48 @@ def roofline_frac(achieved, peak):
     its real name and `frac` is null (the utilisation figure is executed_frac_of_peak)."""
     r = achieved / peak
     return {"frac": r} if r <= 1.0 else {"frac": None, "dense_equiv_ratio": r}
+
+
+def kept_rows(c_eta, state, delta, N, reach_step, margin=1e-3):
+    """LDCBF rows that stay in each problem after the presolve (include/lipmpc.h: LIPMPC_FLAG_NO_PRESOLVE), recomputed on
+    the host from the (c, eta) rows the launch reports."""
+    eta, c = c_eta[:, :, 2:], c_eta[:, :, :2]
+    h0 = np.einsum("bjc,bjc->bj", eta, state[:, [0, 2]][:, None, :] - c) - delta[:, None]
+    pres = np.any(eta != 0.0, axis=2)
+    es = np.sqrt((eta ** 2).sum(2)) * reach_step
+    kept = np.zeros(h0.shape, int)
+    for k in range(1, N + 1):
+        kept += pres & ~(h0 > es * k + margin)
+    return kept.sum(1)
+
+
+def presolve_accounting(lipmpc, P, solver, inp, out, kern_ms, peak, steps, dev):
+    """What the dense convention of `roofline.frac` credits once the presolve removes rows (VERDICT r3 / ADVICE): (1) the same
+    batch through the kernel that keeps EVERY row (LIPMPC_FLAG_NO_PRESOLVE) -- there the dense count prices rows that are
+    really in the solve: frac_no_presolve; (2) the dense count on the rows the presolve KEEPS, with this run's iterations and
+    time: frac_on_kept_rows."""
+    import dataclasses
+    N, n_obs = P.N, P.n_obs_max
+    args = (inp["state"], inp["goal"], inp["foot"], inp["obs_xy"], inp["obs_nv"], inp["delta"])
+    full = lipmpc.BatchedLipMpc(dataclasses.replace(P, flags=P.flags | lipmpc.FLAG_NO_PRESOLVE), dev.index)
+    o = full.alloc_outputs(args[0].shape[0])
+    ms_full = _events_ms(lambda k: full.plan_step_batch(*args, out=o), max(5, steps // 2), dev)
+    it_full = o["iters"].cpu().numpy().astype(np.float64)
+    fl_full = f_iter(2 * N, 9 * N + N * n_obs) * float(it_full.sum())
+    beta = np.sqrt(P.g / P.h_com)
+    dx = max(abs(P.l_max[0]), abs(P.l_min[0])); dy = max(abs(P.l_max[1]), abs(P.l_min[1])) + abs(P.ell)
+    rows = kept_rows(out["c_eta"].cpu().numpy(), inp["state"].cpu().numpy(), inp["delta"].cpu().numpy(), N, float(np.hypot(dx, dy)))
+    it = out["iters"].cpu().numpy().astype(np.float64)
+    fl_kept = float(np.sum(it * np.array([f_iter(2 * N, 9 * N + r) for r in rows])))
+    return {"frac_no_presolve": fl_full / (ms_full * 1e-3) / 1e12 / peak, "kernel_ms_no_presolve": ms_full,
+            "mean_iters_no_presolve": float(it_full.mean()), "flops_per_launch_algorithmic_no_presolve": fl_full,
+            "frac_on_kept_rows": fl_kept / (kern_ms * 1e-3) / 1e12 / peak, "mean_ldcbf_rows_kept": float(rows.mean()),
+            "ldcbf_rows_before_presolve": N * n_obs,
+            "frac_note": "frac = SURVEY 8d dense count over ALL 9N + N n_obs rows x this run's iterations / this run's time (the bench "
+                         "contract); the presolve removes most LDCBF rows before the solve, so frac credits rows the algorithm no longer "
+                         "touches: frac_no_presolve = the same batch through the kernel that keeps every row (its own iterations and "
+                         "time), frac_on_kept_rows = the dense count on the rows actually in the solve; executed_frac_of_peak = FP64 "
+                         "instructions the hardware executed"}
 
 
 def transfer_times(inp, out, dev, kern_ms):
@@ -314,7 +358,7 @@ def main():
         order_detail["one_step_stale_order"] = B * args.steps / elapsed
     # the answers of the batch itself, with the certificate margins the CPU check filters on (outside the timed region:
     # the identification margin costs logarithms)
-    out = solver.plan_step_batch(state, goal, foot, obs_xy, obs_nv, delta, with_diag=True, with_working=True)
+    out = solver.plan_step_batch(state, goal, foot, obs_xy, obs_nv, delta, with_diag=True, with_working=True, with_c_eta=n_obs > 0)
     torch.cuda.synchronize(dev)
     status = out["status"].cpu().numpy()
     iters = out["iters"].cpu().numpy()
@@ -390,8 +434,22 @@ def main():
                                  "instruction counters of the same launch (profiles/), a utilisation figure, whereas "
                                  "frac prices the work a dense solver would do"},
         }
+        if world == 1 and n_obs > 0 and not (P.flags & (lipmpc.FLAG_INTERIOR | lipmpc.FLAG_NO_PRESOLVE)):
+            res["roofline"].update(presolve_accounting(lipmpc, P, solver, inp, out, kern_ms, peak, args.steps, dev))
         if world == 1:
             res["rollout"] = rollout_throughput(lipmpc, walker, obs_xy, obs_nv, goal, delta, dev)
+            rec = _traffic_record(f"rollout_N{N}_obs{n_obs}_B{B}_k40")
+            if rec:      # builder's PMC passes over this very launch (tools/profile_round.sh rollout)
+                ms_r = res["rollout"]["ms"]
+                res["rollout"]["roofline"] = {
+                    "bound": "valu_fp64", "kernel": "rollout_kernel", "kernel_ms": ms_r, "peak": peak, "unit": "TFLOP/s",
+                    "achieved": f_iter(2 * N, 9 * N + N * n_obs) * res["rollout"]["mean_iters_per_step"] * res["rollout"]["mpc_steps_solved"] / (ms_r * 1e-3) / 1e12,
+                    "frac": f_iter(2 * N, 9 * N + N * n_obs) * res["rollout"]["mean_iters_per_step"] * res["rollout"]["mpc_steps_solved"] / (ms_r * 1e-3) / 1e12 / peak,
+                    "traffic": rec.get("hbm_bytes"), "executed_fp64_flops_per_launch": rec.get("executed_fp64_flops"),
+                    "executed_frac_of_peak": (rec.get("executed_fp64_flops") or 0.0) / (ms_r * 1e-3) / 1e12 / peak,
+                    "wave_alive_fraction": rec.get("wave_alive_fraction"),
+                    "note": "the closed-loop kernel runs the interior mode: every present LDCBF row is in every solve, so the dense "
+                            "count prices rows that are really there; traffic / executed flops: profiles/traffic.json (builder's PMC run)"}
         if world == 1 and args.all_configs:
             # the opt-in warm start of the closed loop: fewer iterations, more live state, not faster in wall time
             warm_walker = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5,
@@ -410,6 +468,14 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _traffic_record(key):
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
+        return rec if isinstance(rec, dict) else None
+    except Exception:
+        return None
 
 
 def rollout_throughput(lipmpc, walker, obs_xy, obs_nv, goal, delta, dev, k_max=40):
@@ -467,6 +533,27 @@ def other_configs(lipmpc, synth, dev, full=False):
     several robots (different states) so that the host-side generator stays short.  full: + the round-1 form of config 5
     (rings through HBM) and the closed-loop fleet."""
     out = {}
+    peak = fp64_peak()[0]
+    # config 2 on the REFERENCE's own obstacle stream (SURVEY 8d): the 256 fields its generate_obstacles produced (committed
+    # fixture tests/golden/fields_cfg2.npz, made by importing the reference), 16 robots per field at different walk steps --
+    # next to the same recipe on 256 fields of the restated generator `value` uses (validated in distribution by the tests)
+    gold = os.path.join(ROOT, "tests", "golden", "fields_cfg2.npz")
+    if os.path.exists(gold):
+        B, N, n_obs = 4096, 8, 10
+        d = np.load(gold)
+        rec = {}
+        for name, fields in (("reference_fields", (d["rings"], d["nv"])), ("synthetic_fields_same_recipe", None)):
+            inp = make_inputs(lipmpc, synth, B, N, n_obs, 0, 0, dev, dev.index, n_fields=256, fields=fields)
+            solver = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5), dev.index)
+            o = solver.alloc_outputs(B)
+            ms = _events_ms(lambda k: solver.plan_step_batch(inp["state"], inp["goal"], inp["foot"], inp["obs_xy"], inp["obs_nv"], inp["delta"], out=o), 20, dev)
+            st, it = o["status"].cpu().numpy(), o["iters"].cpu().numpy()
+            flops = f_iter(2 * N, 9 * N + N * n_obs) * float(it.sum())
+            rec[name] = {"ms_per_step": ms, "solves_per_s": B / ms * 1e3, "mean_iters": float(it.mean()), "max_iters": int(it.max()),
+                         "solved_frac": float(np.isin(st, (0, 4)).mean()), "roofline_frac": flops / (ms * 1e-3) / 1e12 / peak}
+        out["config2_reference_generator_fields"] = {"batch": B, "fields": 256, **rec,
+                                                     "source": "tests/golden/fields_cfg2.npz = generate_obstacles of the imported reference (tests/golden/make_golden.py)"}
+        del inp, solver, o
     # config 3 on one GPU: 32768 robots at N = 8 / 10 obstacles, on the schedule (8 rounds of waves)
     B, N, n_obs = 32768, 8, 10
     inp = make_inputs(lipmpc, synth, B, N, n_obs, 50000, 7, dev, dev.index, n_fields=2048)
@@ -474,7 +561,6 @@ def other_configs(lipmpc, synth, dev, full=False):
     ms_s, ms_i, o = _scheduled_ms(solver, inp["walker"], inp, B, dev)
     st, it = o["status"].cpu().numpy(), o["iters"].cpu().numpy()
     flops = f_iter(2 * N, 9 * N + N * n_obs) * float(it.sum())
-    peak = fp64_peak()[0]
     out["config3_32768_on_one_gpu"] = {"batch": B, "ms_per_step": ms_i, "solves_per_s": B / ms_i * 1e3, "launch_order": "index order",
                                        "solves_per_s_scheduled_one_step_stale": B / ms_s * 1e3,
                                        "mean_iters": float(it.mean()), "status_hist": {str(k): int(v) for k, v in zip(*np.unique(st, return_counts=True))},
@@ -485,6 +571,11 @@ def other_configs(lipmpc, synth, dev, full=False):
     inp = make_inputs(lipmpc, synth, B, N, n_obs, 70000, 5, dev, dev.index, n_fields=512, walk_steps=20)
     solver = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5), dev.index)
     ms_s, ms_i, o = _scheduled_ms(solver, inp["walker"], inp, B, dev)
+    class_counts = solver._ws[:5].cpu().numpy().tolist() if getattr(solver, "_ws", None) is not None else None
+    single = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5), dev.index)
+    single.auto_workspace = False        # the one dispatching kernel of rounds 1-3 (its bodies share a register allocation: scratch)
+    o1 = single.alloc_outputs(B)
+    ms_single = _events_ms(lambda k: single.plan_step_batch(inp["state"], inp["goal"], inp["foot"], inp["obs_xy"], inp["obs_nv"], inp["delta"], out=o1), 6, dev)
     st, it = o["status"].cpu().numpy(), o["iters"].cpu().numpy()
     flops = f_iter(2 * N, 9 * N + N * n_obs) * float(it.sum())
     traffic = executed = None
@@ -494,6 +585,9 @@ def other_configs(lipmpc, synth, dev, full=False):
     except Exception:
         pass
     out["config4_N16_50obs"] = {"batch": B, "ms_per_step": ms_i, "solves_per_s": B / ms_i * 1e3, "launch_order": "index order",
+                                "launch": "split: classify -> per-body index lists -> one kernel per solver body (lipmpc_set_workspace)",
+                                "problems_per_body_1_2_4_13_25_slots": class_counts,
+                                "ms_per_step_single_dispatching_kernel": ms_single, "solves_per_s_single_dispatching_kernel": B / ms_single * 1e3,
                                 "solves_per_s_scheduled_one_step_stale": B / ms_s * 1e3,
                                 "mean_iters": float(it.mean()), "max_iters": int(it.max()),
                                 "status_hist": {str(k): int(v) for k, v in zip(*np.unique(st, return_counts=True))},
@@ -534,6 +628,36 @@ def other_configs(lipmpc, synth, dev, full=False):
                             "schedule": "heaviest first by the reading counts of the neighbouring sample (robots moved one step)",
                             "mean_inferred_obstacles": float(sen["n_inferred"].double().mean()),
                             "overflow": int(sen["overflow"].sum())}
+    # config 5 on PER-ROBOT maps of the reference's unknown-environment scenario shape (Scenario.load_scenario(CROWDED, start (0,0),
+    # goal (4,3.5), 20 obstacles, range (-1,6)^2, delta 1: simulation_1.py:195-232): 256 distinct maps, 16 robots each, every
+    # robot somewhere in its map's box outside the obstacles (clearance 0.05)
+    n_maps, n_env = 256, 20
+    mxy, mnv = synth.synthetic_fields(n_maps, n_env, -1.0, 6.0, (0.0, 0.0), (4.0, 3.5), seed=77, delta=1.0)
+    rng = np.random.default_rng(5)
+    pos_h = np.zeros((B, 2))
+    for b in range(B):
+        m = b % n_maps
+        polys = [mxy[m, j, : mnv[m, j]] for j in range(n_env) if mnv[m, j] > 0]
+        while True:
+            p = rng.uniform(-1.0, 6.0, 2)
+            if all(synth._dist_point_poly(p, q) > 0.05 and not synth._inside(p, q) for q in polys):
+                break
+        pos_h[b] = p
+    env_xy = torch.as_tensor(np.tile(mxy, (B // n_maps, 1, 1, 1)), device=dev).contiguous()
+    env_nv = torch.as_tensor(np.tile(mnv, (B // n_maps, 1)), device=dev).contiguous()
+    state_m = torch.zeros((B, 5), dtype=torch.float64, device=dev)
+    state_m[:, 0] = torch.as_tensor(pos_h[:, 0], device=dev); state_m[:, 2] = torch.as_tensor(pos_h[:, 1], device=dev)
+    goal_m = torch.tensor([[4.0, 3.5]], dtype=torch.float64, device=dev).repeat(B, 1).contiguous()
+    ms_scan_m = _time_ms(lambda: sensor.sense(state_m, noise, out=sen, schedule=None, env_xy=env_xy, env_nv=env_nv))
+    ms_step_m = _time_ms(lambda: solver.plan_step_batch_c_eta(state_m, goal_m, foot, sen["c_eta"], None, out=o, overflow=sen["overflow"]))
+    stm = o["status"].cpu().numpy()
+    out["config5_lidar_per_robot_maps"] = {"batch": B, "maps": n_maps, "obstacles_per_map_mean": float((mnv > 0).sum(1).mean()),
+                                           "ms_scan": ms_scan_m, "ms_step": ms_step_m, "robot_steps_per_s": B / (ms_scan_m + ms_step_m) * 1e3,
+                                           "mean_inferred_obstacles": float(sen["n_inferred"].double().mean()), "overflow": int(sen["overflow"].sum()),
+                                           "status_hist": {str(k): int(v) for k, v in zip(*np.unique(stm, return_counts=True))},
+                                           "maps_like": "Scenario.load_scenario(CROWDED, (0,0), (4,3.5), 20, range (-1,6)^2): simulation_1.py:195-232",
+                                           "launch_order": "index order"}
+    sensor.sense(state, noise, out=sen, schedule=None)
     if not full:
         return out
     # the two-launch form of round 1 for comparison: rings through HBM, geometry front end in the step kernel

@@ -348,7 +348,12 @@ struct RowFlags {
 // contraction off so that comparisons see the same roundings as the CPU oracle
 // ------------------------------------------------------------------------------------------
 struct ClosestPoint { double cx, cy, ex, ey; int degenerate; };      // returned in registers: no stack traffic for the call
-template <class RingPtr>
+// The per-edge arithmetic (two IEEE square roots and a division: ~100 dependent instructions) of EU edges runs side by side
+// -- independent chains the single wave of a SIMD can overlap -- and the comparisons that pick the closest edge and count the
+// crossings follow in edge order: the same operations on the same operands in the same order as the plain edge loop of the
+// oracles, hence the same bits; only the latency of the chains is shared (3.3 -> 1.x us per 10 pentagons at one wave per SIMD).
+// EU = 1 (the closed-loop kernel, whose register file is full): the plain loop.
+template <int EU, class RingPtr>
 __device__ __forceinline__ ClosestPoint closest_point_impl(RingPtr ring, int nv, double px, double py) {
 #pragma clang fp contract(off)
   double best = INFINITY;
@@ -358,30 +363,37 @@ __device__ __forceinline__ ClosestPoint closest_point_impl(RingPtr ring, int nv,
   bool inside = false;
   double x0v = ring[2 * (nv - 1)], y0v = ring[2 * (nv - 1) + 1];
   bool f0 = y0v >= py;
-  for (int i = 0; i < nv; ++i) {
-    double ax = ring[2 * i], ay = ring[2 * i + 1];
-    int i1 = (i + 1 == nv) ? 0 : i + 1;
-    double bx = ring[2 * i1], by = ring[2 * i1 + 1];
-    double dx = bx - ax, dy = by - ay;
-    double nrm = sqrt(dx * dx + dy * dy);
-    double den = nrm * nrm;                      // sqrt-then-square, ObstaclesUtils.py:81
-    if (den == 0.0) {
-      r.degenerate = 1;
-    } else {
-      double t = ((px - ax) * dx + (py - ay) * dy) / den;
+  for (int i0 = 0; i0 < nv; i0 += EU) {
+    double ax[EU], ay[EU], qx[EU], qy[EU], dd[EU], den[EU];
+#pragma unroll
+    for (int e = 0; e < EU; ++e) {
+      const int i = (i0 + e < nv) ? i0 + e : i0;            // (an edge past the ring's end repeats edge i0: computed, never looked at)
+      ax[e] = ring[2 * i]; ay[e] = ring[2 * i + 1];
+      const int i1 = (i + 1 == nv) ? 0 : i + 1;
+      const double bx = ring[2 * i1], by = ring[2 * i1 + 1];
+      const double dx = bx - ax[e], dy = by - ay[e];
+      const double nrm = sqrt(dx * dx + dy * dy);
+      den[e] = nrm * nrm;                          // sqrt-then-square, ObstaclesUtils.py:81
+      double t = ((px - ax[e]) * dx + (py - ay[e]) * dy) / den[e];
       t = fmax(0.0, fmin(1.0, t));
-      double qx = ax + t * dx, qy = ay + t * dy;
-      double ux = qx - px, uy = qy - py;
-      double d = sqrt(ux * ux + uy * uy);
-      if (d < best) { best = d; r.cx = qx; r.cy = qy; }
+      qx[e] = ax[e] + t * dx; qy[e] = ay[e] + t * dy;
+      const double ux = qx[e] - px, uy = qy[e] - py;
+      dd[e] = sqrt(ux * ux + uy * uy);
     }
-    // crossing test of edge (ring[i-1] -> ring[i]) with the +X ray (matplotlib Path.contains_point)
-    bool f1 = ay >= py;
-    if (f0 != f1) {
-      bool hit = ((ay - py) * (x0v - ax) >= (ax - px) * (y0v - ay)) == f1;
-      if (hit) inside = !inside;
+#pragma unroll
+    for (int e = 0; e < EU; ++e) {
+      if (i0 + e < nv) {
+        if (den[e] == 0.0) r.degenerate = 1;
+        else if (dd[e] < best) { best = dd[e]; r.cx = qx[e]; r.cy = qy[e]; }
+        // crossing test of edge (ring[i-1] -> ring[i]) with the +X ray (matplotlib Path.contains_point)
+        const bool f1 = ay[e] >= py;
+        if (f0 != f1) {
+          const bool hit = ((ay[e] - py) * (x0v - ax[e]) >= (ax[e] - px) * (y0v - ay[e])) == f1;
+          if (hit) inside = !inside;
+        }
+        x0v = ax[e]; y0v = ay[e]; f0 = f1;
+      }
     }
-    x0v = ax; y0v = ay; f0 = f1;
   }
   double nx = px - r.cx, ny = py - r.cy;
   double nn = sqrt(nx * nx + ny * ny);
@@ -393,7 +405,7 @@ __device__ __forceinline__ ClosestPoint closest_point_impl(RingPtr ring, int nv,
 }
 // rings in global memory: out of line (one copy per kernel, result in registers)
 __device__ __noinline__ ClosestPoint closest_point_normal(const double* __restrict__ ring, int nv, double px, double py) {
-  return closest_point_impl(ring, nv, px, py);
+  return closest_point_impl<1>(ring, nv, px, py);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -466,6 +478,9 @@ template <int G> struct FrontOut {
   int front_flag;                                           // 1: a constant k = 0 row is violated, 2: degenerate geometry,
                                                             // 8: more obstacles keep a row than the solver body holds (split launch: cannot happen)
   int n_rel;                                                // obstacle slots in use (group-uniform)
+#ifdef LIPMPC_PHASE_TIMING
+  unsigned long long t_front = 0ull, t_geom = 0ull;         // wall clock at the end of the front end / of its heading arithmetic
+#endif
 };
 
 // Front end of a step (shared by every solver body of a kernel): theta / omega, closest point and normal per obstacle,
@@ -541,6 +556,9 @@ __device__ __forceinline__ FrontOut<G> front_end(
   // R(theta_a) and W(theta_{a+1}): one sincos per lane (the c = 0 lane of a stage takes theta_a, its partner
   // theta_{a+1}), exchanged inside the stage by the solve
   sincos(c ? th_v : th_r, &F.s_own, &F.c_own);
+#ifdef LIPMPC_PHASE_TIMING
+  F.t_geom = wall_clock64();
+#endif
 
   // ---- obstacles: c_j, eta_j at the current CoM (HumanoidMpc.py:296-319) ----------------------
   // Presolve (oracle: presolve_ldcbf): every feasible p_k lies within k * reach_step of p_0, so the LDCBF row of obstacle j
@@ -596,7 +614,7 @@ __device__ __forceinline__ FrontOut<G> front_end(
           const int nv = PREFETCH ? nv_pre[sw] : obs_nv[oidx];
           there = nv > 0;
           if (there) {
-            const ClosestPoint cp = staged ? closest_point_impl(&lds_ring[j * P.nvert_max][0], nv, p0x, p0y)
+            const ClosestPoint cp = staged ? closest_point_impl<PREFETCH ? 5 : 1>(&lds_ring[j * P.nvert_max][0], nv, p0x, p0y)
                                            : closest_point_normal(obs_xy + oidx * P.nvert_max * 2, nv, p0x, p0y);
             cx = cp.cx; cy = cp.cy; ex = cp.ex; ey = cp.ey;
             degen = cp.degenerate != 0;
@@ -642,6 +660,9 @@ __device__ __forceinline__ FrontOut<G> front_end(
   // the ballast row: n_d copies of 0.q <= s_bar
   F.n_ball = MAXOBS > 0 ? gsum<G>(nd_l) : 0.0;
   F.s_ball = F.n_ball > 0.0 ? gsum<G>(ss_l) / F.n_ball : 0.0;
+#ifdef LIPMPC_PHASE_TIMING
+  F.t_front = wall_clock64();
+#endif
   return F;
 }
 
@@ -671,12 +692,8 @@ __device__ __forceinline__ StepOut step_solve(
   constexpr int NR = R_CBF + NOBS_R;   // local row slots held in registers
   constexpr int MAXOBS = 2 * NOBS_L;
   constexpr int MAXWORDS = 16;         // (9*16 + 17*50 + 63)/64 = 16
-#ifdef LIPMPC_NO_FUSED_DPP
-  constexpr bool FUSED = false, FUSED32 = false;
-#else
   constexpr bool FUSED = (G == 16);    // one-instruction substitution / elimination steps (fmac_bcast)
   constexpr bool FUSED32 = (G == 32);  // the same on two DPP rows per problem (FactorStep32, solve32_*: row-masked chains)
-#endif
   // the fused substitution chains keep 2 x 31 coefficients per lane next to the factor: only the body with two row slots per
   // lane has the registers for them (with 5 or more slots, or inside the closed-loop kernel, they spill to scratch: those
   // keep the unfused substitution)
@@ -873,14 +890,28 @@ __device__ __forceinline__ StepOut step_solve(
   auto factor = [&]() -> bool {
     bool ok = true;
     const int ln = fresh(lane);
-    if constexpr (FUSED || FUSED32) dpp_fence();
+    dpp_fence();
     static_for<0, NV>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      if constexpr (FUSED32) {
+      if constexpr (FUSED) {
+        // One DPP row per problem: pivot chain (broadcast, reciprocal, one Newton step, scaled column), then the NV - 1 - j
+        // updates of the step as one asm statement.  (Issuing the updates BETWEEN the links of the next step's pivot chain --
+        // "lookahead", tried in round 4 -- gains nothing: a dependent FP64 instruction costs 7 cycles against 4.6 for an
+        // independent one, the chain is issue slots, not latency; profiles/r04_dev_tools/r04_iter_cost_lookahead_factorisation.txt.)
+        const double pj = gbcast<G, j>(Krow[j]);
+        ok = ok && (pj > 0.0);
+        const double ip = fast_rcp(pj);
+        const double nf = zero_unless(ln > j, Krow[j] * -ip);
+        ipiv = (ln == j) ? ip : ipiv;
+        Xl[j] = nf;
+        FactorStep<NV, j>::run(Krow, nf);
+      } else {
         // Two DPP rows per problem.  Row j of the Schur complement equals its column j, and the column is lane-distributed
         // (lane cc holds S[cc][j] in Krow[j]): ONE cross-row exchange per step makes both 16-lane halves of the column
         // visible in every row, after which each update S[l][cc] -= (S[l][j] / p_j) S[cc][j] is one v_fmac_f64_dpp with the
-        // broadcast of S[cc][j] as its DPP operand (LDL^T form; see the unfused branch below for why not Cholesky form)
+        // broadcast of S[cc][j] as its DPP operand.  (LDL^T form: a Cholesky-form update g_l g_cc with g = S[.][j] / sqrt(p_j)
+        // keeps the two triangles bit-identical but breaks down -- pivot <= 0 -- on 3 % of the N = 16 / 50-obstacle problems
+        // where this form does not.)
         double cA, cB;                                    // S[0..15][j], S[16..31][j] by local lane position
         rowpair(Krow[j], cA, cB);
         const double pj = bc16(std::integral_constant<int, (j & 15)>{}, j < 16 ? cA : cB);
@@ -890,42 +921,6 @@ __device__ __forceinline__ StepOut step_solve(
         const double ng = zero_unless(ln > j, Krow[j] * -ip);
         if constexpr (FUSED32_SOLVE) Xl[j] = ng;
         FactorStep32<j>::run(Krow, cA, cB, ng);
-      } else if constexpr (FUSED) {
-        const double pj = gbcast<G, j>(Krow[j]);
-        ok = ok && (pj > 0.0);
-        const double ip = fast_rcp(pj);
-        const double nf = zero_unless(ln > j, Krow[j] * -ip);
-        ipiv = (ln == j) ? ip : ipiv;
-        Xl[j] = nf;
-        FactorStep<NV, j>::run(Krow, nf);
-      } else if constexpr (G == 16) {
-        const double pj = gbcast<G, j>(Krow[j]);
-        ok = ok && (pj > 0.0);
-        const double ip = fast_rcp(pj);
-        const double f = zero_unless(ln > j, Krow[j] * ip);
-        ipiv = (ln == j) ? ip : ipiv;
-        static_for<j + 1, NV>([&](auto cc_) {
-          constexpr int cc = decltype(cc_)::value;
-          Krow[cc] = fma(-f, gbcast<G, j>(Krow[cc]), Krow[cc]);
-        });
-      } else {
-        // Two DPP rows per problem.  Row j of the Schur complement equals its column j, and the column is
-        // lane-distributed (lane cc holds S[cc][j] in Krow[j]): ONE cross-row exchange per step makes both
-        // 16-lane halves of the column visible in every row, after which each needed entry is an in-row broadcast.
-        double cA, cB;                                    // S[0..15][j], S[16..31][j] by local lane position
-        rowpair(Krow[j], cA, cB);
-        const double pj = bc16(std::integral_constant<int, (j & 15)>{}, j < 16 ? cA : cB);
-        ok = ok && (pj > 0.0);
-        // LDL^T-form update S[l][cc] -= (S[l][j] / p_j) S[cc][j], the pivot row read through its mirror image, the
-        // column.  (A Cholesky-form update g_l g_cc with g = S[.][j] / sqrt(p_j) keeps the two triangles bit-identical,
-        // but breaks down -- pivot <= 0 -- on 3 % of the N=16 / 50-obstacle problems where this form does not.)
-        const double ip = fast_rcp(pj);
-        ipiv = (ln == j) ? ip : ipiv;
-        const double g = zero_unless(ln > j, Krow[j] * ip);
-        static_for<j + 1, NV>([&](auto cc_) {
-          constexpr int cc = decltype(cc_)::value;
-          Krow[cc] = fma(-g, bc16(std::integral_constant<int, (cc & 15)>{}, cc < 16 ? cA : cB), Krow[cc]);
-        });
       }
     });
     if constexpr (FUSED || FUSED32_SOLVE) {
@@ -961,23 +956,6 @@ __device__ __forceinline__ StepOut step_solve(
       rowpair(x, lo_rep, hi_rep);                         // hi_rep: x_16..x_31
       x = solve32_bwd_x(x, hi_rep, Yu);
       return solve32_bwd_lo(x, Yu);
-    } else if constexpr (G == 16) {
-      // forward Lt w = b: w_j = b_j / p_j, b_l -= Lt[l][j] w_j (l > j); lane j's b is final after step j
-      static_for<0, NV>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        const double wj = zero_unless(ln > j, gbcast<G, j>(b * ipiv));
-        b = fma(-Krow[j], wj, b);
-      });
-      const double w = b * ipiv;
-      // backward Lt^T x = D w: x_j = w_j - (1/p_j) sum_{l>j} Lt[l][j] x_l, lane j holds Lt[l][j] in Krow[l];
-      // lane j's acc is final once step j+1 is done
-      double acc = 0.0;
-      static_rfor<NV, 0>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        const double xj = zero_unless(ln < j, gbcast<G, j>(fma(-ipiv, acc, w)));
-        acc = fma(Krow[j], xj, acc);
-      });
-      return fma(-ipiv, acc, w);
     } else {
       // Same recurrences, organised so that the substitution chain stays inside one DPP row at a time:
       // columns 0..15 are eliminated among the lanes of row 0, the lanes of row 1 catch up on those 16 columns
@@ -1695,6 +1673,8 @@ __device__ __forceinline__ StepOut step_solve(
       o[24] = 10.0 * (double)(wall_clock64() - in.t_start_wall);
       o[25] = (double)((unsigned long long)__builtin_readcyclecounter() - in.t_start_ticks);
       o[26] = it_w; o[27] = rd_w; o[28] = 1.0;
+      o[29] = 10.0 * (double)(F.t_front - in.t_start_wall);      // kernel entry -> end of the front end
+      o[30] = 10.0 * (double)(F.t_geom - in.t_start_wall);       // kernel entry -> headings done (loads + atan2 + sincos)
     }
   }
 #endif

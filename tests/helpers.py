@@ -126,6 +126,43 @@ def convex_ring(pts):
     return np.array(lo[:-1] + up[:-1])
 
 
+def field_features(xy, nv):
+    """Shape statistics of obstacle fields [B,n_obs,v_max,2] / [B,n_obs]: vertex-count shares (3, 4, 5), polygon areas,
+    nearest-neighbour distances of the polygon centres, centre coordinates, polygons per field."""
+    B, n = nv.shape
+    share = np.bincount(nv.ravel(), minlength=6)[3:6] / max(int((nv > 0).sum()), 1)
+    area, near, cen = [], [], []
+    for b in range(B):
+        cs = []
+        for j in range(n):
+            p = xy[b, j, : nv[b, j]]
+            if len(p) < 3:
+                continue
+            x, y = p[:, 0], p[:, 1]
+            area.append(0.5 * abs(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1))))
+            cs.append(p.mean(0))
+        cs = np.array(cs)
+        cen.append(cs)
+        D = np.sqrt(((cs[:, None] - cs[None]) ** 2).sum(2)) + np.eye(len(cs)) * 1e9
+        near += list(D.min(1))
+    return dict(vertex_share=share, area=np.array(area), nearest=np.array(near), centres=np.concatenate(cen), per_field=(nv > 0).sum(1))
+
+
+def kept_rows_after_presolve(c_eta, state, delta, N):
+    """Rows of the LDCBF block that stay in the problem after the presolve (oracle: presolve_ldcbf), per problem, from the
+    (c, eta) rows a launch reports: obstacle j keeps its rows of the stages k with h0_j <= |eta_j| k reach_step + margin."""
+    step = O.reach_step(O.Params(N=N))
+    eta, c = c_eta[:, :, 2:], c_eta[:, :, :2]
+    p0 = state[:, [0, 2]]
+    h0 = np.einsum("bjc,bjc->bj", eta, p0[:, None, :] - c) - np.asarray(delta)[:, None]
+    pres = np.any(eta != 0.0, axis=2)
+    es = np.sqrt((eta ** 2).sum(2)) * step
+    kept = np.zeros(h0.shape, int)
+    for k in range(1, N + 1):
+        kept += pres & ~(h0 > es * k + O.SCREEN_MARGIN)
+    return kept.sum(1), (kept > 0).sum(1)
+
+
 def crowded_batch(N, n_obs, B, seed):
     """Robots in the middle of a ring of small obstacles -- 0 to n_obs of them within reach of the horizon, a different number
     per robot, anywhere in the obstacle list -- so that after the presolve the problems of one batch need every solver body

@@ -60,6 +60,8 @@ def run(tag, N, n_obs, state, goal, foot, obs_xy, obs_nv, delta, flags=0, max_it
         print(f"   {k:2d} {NAMES[k]:26s} {sec[:, k].mean() / 1e3:9.2f} us/wave ({100 * sec[:, k].sum() / tot.sum():5.1f} %), single-group part {100 * solo[:, k].sum() / max(sec[:, k].sum(), 1):5.1f} %{per}")
     print(f"   per wave iteration {sec[:, :7].sum() / max(it_w.sum(), 1) / 1e3:.2f} us, per wave round {sec[:, 7:10].sum() / max(rd_w.sum(), 1) / 1e3:.2f} us, "
           f"fixed (front end + outputs) {sec[:, 10:].sum(1).mean() / 1e3:.2f} us")
+    print(f"   inside 'front end': kernel entry -> headings done {w[:, 30].mean() / 1e3:.2f} us, -> front end done {w[:, 29].mean() / 1e3:.2f} us, "
+          f"-> first iteration {sec[:, 10].mean() / 1e3:.2f} us")
     for i in np.argsort(-life)[:6]:                     # the waves the launch waits for
         print(f"   slow wave: {life[i] / 1e3:7.1f} us  iterations {it_w[i]:3.0f} x {sec[i, :7].sum() / max(it_w[i], 1) / 1e3:5.2f} us  rounds {rd_w[i]:2.0f} x "
               f"{sec[i, 7:10].sum() / max(rd_w[i], 1) / 1e3:5.2f} us (K+factor {sec[i, 7] / 1e3:.1f}, equality solve {sec[i, 8] / 1e3:.1f}, ratio/exchange {sec[i, 9] / 1e3:.1f})  "
