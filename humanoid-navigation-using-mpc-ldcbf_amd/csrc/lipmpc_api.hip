@@ -86,41 +86,53 @@ __global__ __launch_bounds__(1024) void order_by_cost_kernel(long B, int32_t* __
   if (threadIdx.x == 0) sched[SCHED_VALID] = (int32_t)B;
 }
 
-// Index lists per class from the classes: a stable counting sort in one workgroup (every thread owns a contiguous run of
-// problems: per-class counts, an exclusive scan over the threads, then the writes) -- stable, so the lists, and with them which
-// problems share a wave, are a function of the batch alone.
-__global__ __launch_bounds__(1024) void split_bin_kernel(long B, int32_t* __restrict__ ws) {
-  __shared__ int cnt_[SPLIT_CLASSES][1024];
-  __shared__ int base_[SPLIT_CLASSES];
-  const int t = threadIdx.x, T = blockDim.x;
-  const long per = (B + T - 1) / T, lo = min((long)t * per, B), hi = min(lo + per, B);
-  const int32_t* cls = ws + SPLIT_HEAD;
-  int mine[SPLIT_CLASSES];
-#pragma unroll
-  for (int c = 0; c < SPLIT_CLASSES; ++c) mine[c] = 0;
-  for (long i = lo; i < hi; ++i) {
-    const int k = cls[i];
-#pragma unroll
-    for (int c = 0; c < SPLIT_CLASSES; ++c) mine[c] += (k == c) ? 1 : 0;
-  }
-#pragma unroll
-  for (int c = 0; c < SPLIT_CLASSES; ++c) cnt_[c][t] = mine[c];
+// Index lists per class from the sort keys (class, cost bucket): a STABLE counting sort in one workgroup -- every thread owns a
+// contiguous run of problems and counts its keys (bytes in LDS); per key one wave scans the counts over the threads (eight
+// threads' bytes per lane as one 64-bit word, a wave prefix sum over the lanes); then the writes -- so the lists, and with them
+// which problems share a wave, are a function of the batch alone.  The list of a class is the concatenation of its buckets,
+// dearest first.
+constexpr int BIN_THREADS = 512;
+constexpr int BIN_KEYS = SPLIT_CLASSES * SPLIT_BUCKETS;
+constexpr long BIN_MAX_B = 255L * BIN_THREADS;          // a thread's run holds at most 255 problems (byte counters)
+__device__ __forceinline__ int bin_key(int k) { return min(max(k, 0), BIN_KEYS - 1); }
+__global__ __launch_bounds__(BIN_THREADS) void split_bin_kernel(long B, int32_t* __restrict__ ws) {
+  __shared__ __attribute__((aligned(8))) unsigned char cnt_[BIN_KEYS][BIN_THREADS];
+  __shared__ int start_[BIN_KEYS][BIN_THREADS / 8];      // problems with this key in the runs of the threads before lane's eight
+  __shared__ int total_[BIN_KEYS], base_[BIN_KEYS];
+  const int t = threadIdx.x;
+  const long per = (B + BIN_THREADS - 1) / BIN_THREADS, lo = min((long)t * per, B), hi = min(lo + per, B);
+  const int32_t* key = ws + SPLIT_HEAD;
+  unsigned* z = reinterpret_cast<unsigned*>(&cnt_[0][0]);
+  for (int i = t; i < BIN_KEYS * BIN_THREADS / 4; i += BIN_THREADS) z[i] = 0u;
   __syncthreads();
-  if (t < SPLIT_CLASSES) {                       // one thread per class scans its row (1024 adds: nothing next to a solve)
+  for (long i = lo; i < hi; ++i) cnt_[bin_key(key[i])][t] += 1;      // (own column: no race)
+  __syncthreads();
+  const int wave = t >> 6, lane = t & 63;
+  for (int k = wave; k < BIN_KEYS; k += BIN_THREADS / 64) {
+    const unsigned long long w = *reinterpret_cast<const unsigned long long*>(&cnt_[k][8 * lane]);
+    int mine = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) mine += (int)((w >> (8 * u)) & 0xffull);
+    int incl = mine;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_up(incl, m, 64); if (lane >= m) incl += o; }
+    start_[k][lane] = incl - mine;
+    if (lane == 63) total_[k] = incl;
+  }
+  __syncthreads();
+  if (t < SPLIT_CLASSES) {
     int run = 0;
-    for (int k = 0; k < T; ++k) { const int v = cnt_[t][k]; cnt_[t][k] = run; run += v; }
-    base_[t] = run;
+    for (int q = 0; q < SPLIT_BUCKETS; ++q) { base_[t * SPLIT_BUCKETS + q] = run; run += total_[t * SPLIT_BUCKETS + q]; }
     ws[t] = run;
   }
   __syncthreads();
-  int pos[SPLIT_CLASSES];
-#pragma unroll
-  for (int c = 0; c < SPLIT_CLASSES; ++c) pos[c] = cnt_[c][t];
   for (long i = lo; i < hi; ++i) {
-    const int k = cls[i];
-#pragma unroll
-    for (int c = 0; c < SPLIT_CLASSES; ++c)
-      if (k == c) { ws[SPLIT_HEAD + B * (1 + c) + pos[c]] = (int32_t)i; ++pos[c]; }
+    const int k = bin_key(key[i]);
+    // position: the key's base inside its class list + the runs of the earlier threads + this thread's earlier problems of the key
+    int pos = base_[k] + start_[k][t >> 3];
+    for (int u = t & ~7; u < t; ++u) pos += cnt_[k][u];
+    for (long j = lo; j < i; ++j) pos += (bin_key(key[j]) == k) ? 1 : 0;
+    ws[SPLIT_HEAD + B * (1 + k / SPLIT_BUCKETS) + pos] = (int32_t)i;
   }
 }
 
@@ -227,6 +239,8 @@ int lipmpc_set_workspace(lipmpc_handle* h, void* workspace, int64_t capacity) {
   if (h->ws && !h->have_streams) {
     if (hipSetDevice(h->device) != hipSuccess) return LIPMPC_E_HIP;
     bool ok = hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming) == hipSuccess;
+    // (plain streams: side streams of the highest priority, tried so that the dearer bodies' waves are placed first, made the
+    // launch 35 % slower -- the high-priority queues delay the next launch's classification and the fork / join events)
     for (int i = 0; ok && i < SPLIT_CLASSES - 1; ++i)
       ok = hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking) == hipSuccess &&
            hipEventCreateWithFlags(&h->join_ev[i], hipEventDisableTiming) == hipSuccess;
@@ -253,7 +267,7 @@ static int plan_step_impl(lipmpc_handle* h, int64_t B, const double* state, cons
   if (hipSetDevice(h->device) != hipSuccess) return LIPMPC_E_HIP;
   hipStream_t stream = (hipStream_t)hip_stream;
   int32_t* sched = (h->sched && B <= h->sched_cap) ? h->sched : nullptr;
-  if (h->ws && B <= h->ws_cap && split_capable(h)) {
+  if (h->ws && B <= h->ws_cap && B <= BIN_MAX_B && split_capable(h)) {
     // Split launch: classes -> lists -> one kernel per solver body, side by side.  The rare, long bodies go first on their own
     // streams (a few waves each, they must not queue behind 2048 short ones); the caller's stream takes the 1-slot body and
     // waits for the others.
@@ -263,7 +277,7 @@ static int plan_step_impl(lipmpc_handle* h, int64_t B, const double* state, cons
     int32_t* cost = sched ? sched + SCHED_ORDER + B : nullptr;
     hipLaunchKernelGGL((classify_kernel<32>), dim3(blocks), dim3(WAVE), 0, stream, h->k, (long)B, state, goal, delta, obs_xy, obs_nv,
                        bounds, c_eta_in, ws);
-    hipLaunchKernelGGL(split_bin_kernel, dim3(1), dim3(1024), 0, stream, (long)B, ws);
+    hipLaunchKernelGGL(split_bin_kernel, dim3(1), dim3(BIN_THREADS), 0, stream, (long)B, ws);
     const int top = split_class_of((h->p.n_obs_max + 1) / 2);
 #define LIST(NL, CLS, ST)                                                                                                     \
   launch_solve_list<32, NL, 32>(h->k, (long)B, CLS, ws, state, goal, first_foot, delta, obs_xy, obs_nv, U, X, theta, omega, obj, status, \

@@ -75,6 +75,17 @@ constexpr int SCHED_VALID = 0, SCHED_ORDER = 2, SCHED_COST_BINS = 128;
 // b: B | list of class c: B each].
 constexpr int SPLIT_CLASSES = 5;
 constexpr int SPLIT_HEAD = 8;
+// Inside a class the list is ordered by a COST HINT, dearest first, in SPLIT_BUCKETS steps: a launch of more waves than the GPU
+// holds at once ends when its last wave does, so the long solves should start first, and problems of like cost should share a
+// wave.  Nothing predicts a solve's iteration count well; three quantities the front end has anyway predict it a little
+// (correlation 0.35 with the measured cost on the N = 16 / 50-obstacle batches): the clearance of the nearest obstacle, the
+// number of LDCBF rows the presolve keeps, the robot's speed.  A scheduling hint only: every order gives the same results.
+constexpr int SPLIT_BUCKETS = 16;
+__device__ __forceinline__ int split_cost_bucket(double h0_min, double rows_kept, double speed) {
+  const double us = 190.0 - 37.0 * fmin(fmax(h0_min, 0.0), 0.5) + 0.7 * rows_kept + 22.0 * speed;     // fitted once, in microseconds
+  const int bkt = (int)((236.0 - us) * (1.0 / 4.0));                                                  // 0 = dearest
+  return min(max(bkt, 0), SPLIT_BUCKETS - 1);
+}
 // row slots per lane of the five bodies: 1, 2, 4 in registers, 13 and 25 streamed through LDS -- every one compiles without
 // scratch on its own (a 5- or 7-slot register body does not: 32 / 208 B per lane)
 __host__ __device__ constexpr int split_slots(int cls) { return cls == 0 ? 1 : cls == 1 ? 2 : cls == 2 ? 4 : cls == 3 ? 13 : 25; }
@@ -478,6 +489,8 @@ template <int G> struct FrontOut {
   int front_flag;                                           // 1: a constant k = 0 row is violated, 2: degenerate geometry,
                                                             // 8: more obstacles keep a row than the solver body holds (split launch: cannot happen)
   int n_rel;                                                // obstacle slots in use (group-uniform)
+  double h0_min, rows_kept;                                 // clearance of the nearest obstacle (its row's value at p_0), LDCBF rows in
+                                                            // the solve: what the split launch's cost hint looks at (group-uniform)
 #ifdef LIPMPC_PHASE_TIMING
   unsigned long long t_front = 0ull, t_geom = 0ull;         // wall clock at the end of the front end / of its heading arithmetic
 #endif
@@ -573,6 +586,7 @@ __device__ __forceinline__ FrontOut<G> front_end(
   const bool presolve = !(P.flags & (LIPMPC_FLAG_INTERIOR | LIPMPC_FLAG_NO_PRESOLVE | LIPMPC_FLAG_WARM_START));
   const bool compact = cold;
   double nd_l = 0.0, ss_l = 0.0;          // this lane's share of n_d and of the dropped rows' slack sum
+  double h0min_l = INFINITY, np_l = 0.0;  // ... of the smallest h0 and of the number of present obstacles
   if (lane == 0) *lds_flag_g = 0;
   if constexpr (MAXOBS > 0) {
     if (staged) {
@@ -627,6 +641,8 @@ __device__ __forceinline__ FrontOut<G> front_end(
           h0 = (ex * p0x + ey * p0y) - ec - delta;
           if (degen) atomicOr(lds_flag_g, 2);
           else if (h0 < -P.k0_tol) atomicOr(lds_flag_g, 1);
+          h0min_l = fmin(h0min_l, h0);
+          np_l += 1.0;
           int kf = 1;
           if (presolve) {
             const double es = sqrt(ex * ex + ey * ey) * P.reach_step;
@@ -660,6 +676,11 @@ __device__ __forceinline__ FrontOut<G> front_end(
   // the ballast row: n_d copies of 0.q <= s_bar
   F.n_ball = MAXOBS > 0 ? gsum<G>(nd_l) : 0.0;
   F.s_ball = F.n_ball > 0.0 ? gsum<G>(ss_l) / F.n_ball : 0.0;
+  F.h0_min = INFINITY; F.rows_kept = 0.0;
+  if constexpr (PREFETCH && MAXOBS > 0) {          // (the closed-loop kernel has no use for them)
+    F.h0_min = gmin<G>(h0min_l);
+    F.rows_kept = gsum<G>(np_l) * (double)N - F.n_ball;
+  }
 #ifdef LIPMPC_PHASE_TIMING
   F.t_front = wall_clock64();
 #endif
@@ -1794,7 +1815,10 @@ __global__ __launch_bounds__(WAVE) void classify_kernel(
   const StepIn in = load_step_in(P, pb, prob_raw < B, state, goal, nullptr, delta_in, bounds, nullptr);
   const FrontOut<G> F = front_end<G, SPLIT_MAXOBS>(P, in, obs_xy, obs_nv, nullptr, nullptr, nullptr, c_eta_in, true, lds_ring[grp],
                                                    lds_obs[grp], lds_perm[grp], &lds_flag[grp]);
-  if (in.valid && (threadIdx.x & (G - 1)) == 0) ws[SPLIT_HEAD + pb] = split_class_of((F.n_rel + 1) >> 1);
+  // sort key: class, then the cost hint's bucket (0 = dearest)
+  if (in.valid && (threadIdx.x & (G - 1)) == 0)
+    ws[SPLIT_HEAD + pb] = split_class_of((F.n_rel + 1) >> 1) * SPLIT_BUCKETS +
+                          split_cost_bucket(F.h0_min, F.rows_kept, sqrt(in.v0x * in.v0x + in.v0y * in.v0y));
 }
 
 // One solver body over its class's list: the step kernel with NL row slots per lane and nothing else in its register
@@ -1815,7 +1839,8 @@ __global__ __launch_bounds__(WAVE) void solve_list_kernel(
   constexpr int RING_CAP = (G == 16) ? 64 : 256;
   if (blockDim.x != WAVE) __builtin_trap();
   const int count = ws[cls];
-  if ((long)blockIdx.x * GPW >= count) return;                    // (wave-uniform)
+  if ((long)blockIdx.x * GPW >= count) return;                    // (wave-uniform; no loop over the list: a loop around the step
+                                                                  // costs every body 200-500 B of scratch per lane)
   __shared__ double lds_ring[GPW][RING_CAP][2];
   __shared__ double lds_obs[GPW][SPLIT_MAXOBS][4];
   __shared__ int lds_perm[GPW][SPLIT_MAXOBS];
