@@ -37,7 +37,7 @@ constexpr int NO_ROOT = 0x7fffffff;
 constexpr int SOLO_MIN = 48;        // a cluster of at least this many points gets the whole wave in the hull stage
 constexpr int NCC = 64;             // candidates whose bounding circle is kept for the per-pass sector test
 constexpr int VSTAGE = 64;          // hull vertices staged per cluster (v_max <= VSTAGE)
-// schedule buffer (int32): [B the order is valid for, -, order[B] (robot at launch position i), readings[B] (per robot)]
+// order buffer (int32, scratch of ONE call): [B the order is valid for, -, order[B] (robot at launch position i), weight[B]]
 constexpr int SCHED_VALID = 0, SCHED_ORDER = 2;
 constexpr int NRUN = RMAX / 16;      // runs of 16 consecutive readings
 constexpr int ECAP = 2 * RMAX / 4;  // edges staged per chunk of the ray phase (4 doubles each, in the hull stage's point arrays)
@@ -107,11 +107,11 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
 
   const int lane = threadIdx.x;
   if ((long)blockIdx.x >= B) return;
-  // Which robot this wave scans: the block index, or -- with a schedule (include/lipmpc.h) -- the robot the order left by the
-  // previous launch puts at this position: heaviest first, by reading count.  A scan's length varies 3x with the number
-  // of readings (all-pairs clustering), 4096 robots run in two rounds on the 2048 wave slots, and a heavy robot started
-  // late sets the launch time: 241 us as the robots come, 159 us heaviest first (tools/lidar_order.py).  Any order
-  // gives the same results.
+  // Which robot this wave scans: the block index, or -- with an order buffer (include/lipmpc.h) -- the robot the order
+  // kernel of THIS call put at this position: heaviest first, by an estimate of its reading count (lidar_weight_kernel).  A
+  // scan's length varies 3x with the number of readings (all-pairs clustering), 4096 robots run in two rounds on the 2048 wave
+  // slots, and a heavy robot started late sets the launch time: 241 us as the robots come, 159 us heaviest first by the true
+  // counts (tools/lidar_order.py).  Any order gives the same results.
   long b = blockIdx.x;
   if (sched && sched[SCHED_VALID] == (int)B) {
     const long r = sched[SCHED_ORDER + blockIdx.x];
@@ -658,11 +658,42 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
     g += ng;
   }
   if (lane == 0) { n_inferred[b] = n_out; overflow[b] = ovf; }
-  if (sched && lane == 0) sched[SCHED_ORDER + B + b] = n_pts;      // this robot's weight for the next launch's order
 }
 
-// The order of the NEXT launch from the reading counts this launch left: robots by descending count (counting sort, one
-// workgroup; which of two equally heavy robots comes first is immaterial).
+// Weight of every robot for the launch order of its scan: an ESTIMATE of its reading count from the bounding circles of the
+// obstacles in range -- the rays a circle of radius r at distance d subtends, R / (2 pi) * 2 asin(r / d) (the asin by its
+// argument: the estimate only ranks), scaled by the share of the circle inside the range, summed and capped at R.  Correlation
+// 0.76 with the true counts on a CROWDED-style map, 27 of the 30 heaviest robots in its top 60: enough for
+// "heaviest first", and it costs one obstacle per lane instead of the scan itself.  One wave per robot.
+__global__ __launch_bounds__(64) void lidar_weight_kernel(long B, int R, int n_env, int v_env, long env_stride, double lidar_range,
+                                                          const double* __restrict__ state, const double* __restrict__ env_xy,
+                                                          const int32_t* __restrict__ env_nv, int32_t* __restrict__ sched) {
+  const long b = blockIdx.x;
+  if (b >= B) return;
+  const int lane = threadIdx.x;
+  const double x0 = state[b * 5 + 0], y0 = state[b * 5 + 2];
+  const double* exy = env_xy + b * env_stride * (long)n_env * v_env * 2;
+  const int32_t* env = env_nv + b * env_stride * (long)n_env;
+  double w = 0.0;
+  for (int j = lane; j < n_env; j += 64) {
+    const int nv = min(env[j], v_env);
+    if (nv <= 0) continue;
+    const double* ring = exy + (long)j * v_env * 2;
+    double mx = 0.0, my = 0.0, rad2 = 0.0;
+    for (int e = 0; e < nv; ++e) { mx += ring[2 * e]; my += ring[2 * e + 1]; }
+    mx /= nv; my /= nv;
+    for (int e = 0; e < nv; ++e) { const double dx = ring[2 * e] - mx, dy = ring[2 * e + 1] - my; rad2 = fmax(rad2, dx * dx + dy * dy); }
+    const double rad = sqrt(rad2), d = sqrt((mx - x0) * (mx - x0) + (my - y0) * (my - y0));
+    if (d > lidar_range + rad) continue;
+    const double inside = (d + rad <= lidar_range) ? 1.0 : fmin(1.0, fmax(0.0, (lidar_range + rad - d) / (2.0 * rad + 1e-300)));
+    w += (d <= rad) ? (double)R : (double)R * (1.0 / M_PI) * fmin(1.0, rad / d) * inside;
+  }
+  for (int m = 1; m < 64; m <<= 1) w += __shfl_xor(w, m, 64);
+  if (lane == 0) sched[SCHED_ORDER + B + b] = (int32_t)fmin(w, (double)R);
+}
+
+// The launch order of the scans from the weights: robots by descending weight (counting sort, one workgroup; which of two
+// equally heavy robots comes first is immaterial).
 __global__ __launch_bounds__(1024) void lidar_order_kernel(long B, int32_t* __restrict__ sched) {
   __shared__ int cursor_[RMAX + 1];
   const int32_t* w = sched + SCHED_ORDER + B;
@@ -700,10 +731,17 @@ static int lidar_launch(int device, int64_t B, int32_t resolution, int32_t n_env
 #else
   const int dbg_stop = 0;
 #endif
+  if (schedule && n_env > 0) {
+    // rank the robots first: estimate of the reading counts -> order, heaviest first; the scans then start in that order
+    hipLaunchKernelGGL(lidar_weight_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)hip_stream, (long)B, resolution, n_env, v_env,
+                       (long)(env_shared ? 0 : 1), lidar_range, state, env_xy, env_nv, schedule);
+    hipLaunchKernelGGL(lidar_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, (long)B, schedule);
+  } else {
+    schedule = nullptr;
+  }
   hipLaunchKernelGGL(lidar_sense_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)hip_stream, (long)B, resolution, n_env,
                      v_env, (long)(env_shared ? 0 : 1), lidar_range, eps, min_samples, n_obs_max, v_max, state, env_xy, env_nv,
                      ray_table, noise, obs_xy, obs_nv, c_eta, n_inferred, overflow, hits, labels, schedule, dbg_stop);
-  if (schedule) hipLaunchKernelGGL(lidar_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, (long)B, schedule);
   return hipGetLastError() == hipSuccess ? LIPMPC_OK : LIPMPC_E_HIP;
 }
 

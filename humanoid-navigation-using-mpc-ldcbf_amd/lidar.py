@@ -61,9 +61,9 @@ class LidarSensor:
         return out
 
     def make_schedule(self, B):
-        """A zeroed schedule buffer for ``sense(..., schedule=)`` (lipmpc_lidar_c_eta_batch): hand the same buffer to every
-        scan of the same B robots and each launch starts its robots heaviest first, by the reading counts of the launch
-        before.  A scheduling hint only: results do not depend on it."""
+        """An order buffer for ``sense(..., schedule=)`` (lipmpc_lidar_c_eta_batch): scratch in which the call ranks its B
+        robots by an estimate of their reading counts and from which it starts their scans heaviest first.  Nothing carries
+        over between calls; results do not depend on it."""
         return torch.zeros((int(self.lib.lipmpc_lidar_schedule_words(B)),), dtype=torch.int32, device=self.device)
 
     def sense(self, state, noise=None, with_debug=False, out=None, env_xy=None, env_nv=None, c_eta=False, rings=True,
@@ -72,11 +72,11 @@ class LidarSensor:
         [, hits, labels]).  ``c_eta=True``: the constraint assembly runs in the same launch (lipmpc_lidar_c_eta_batch) and
         the dict carries c_eta [B,n_obs_max,4] = (c, eta) of every inferred hull at the robot's CoM -- what
         ``BatchedLipMpc.plan_step_batch_c_eta`` solves against; with ``rings=False`` the hulls never leave the kernel.
-        ``schedule``: a buffer of ``make_schedule(B)``, None (robots in index order), or "auto" (default): with
-        ``c_eta=True`` the sensor keeps one schedule per (batch size, current stream), so repeated scans of a batch start
-        their robots heaviest first by the previous scan's reading counts.  A scheduling hint only -- any order gives the same
-        results -- but scans that share a schedule BUFFER must be ordered on one stream (the order kernel of one launch
-        rewrites what the next launch reads; a torn order would scan some robots twice and others not at all): a buffer
+        ``schedule``: a buffer of ``make_schedule(B)``, None (robots scanned in index order), or "auto" (default): with
+        ``c_eta=True`` and more than one round of waves the sensor keeps one order buffer per (batch size, current stream) and
+        every scan first ranks its robots (estimated reading counts, heaviest first: two small kernels inside the call).  Any
+        order gives the same results -- but scans that share a BUFFER must be ordered on one stream (the order kernel of one
+        launch rewrites what another launch reads; a torn order would scan some robots twice and others not at all): a buffer
         of ``make_schedule`` handed to launches on two streams, or to two graphs replayed concurrently, is a caller's bug.
         Vertex slots beyond obs_nv keep whatever an earlier call left there when ``out`` is reused.
         ``env_xy`` [B,n_env,v_env,2] / ``env_nv`` [B,n_env] (device tensors): one true map PER ROBOT instead of the
@@ -273,7 +273,7 @@ class UnknownEnvFleet:
                   sen=sn.alloc_outputs(B, rings=False, c_eta=True),      # hulls stay in the scan kernel: only (c, eta) rows reach HBM
                   out=sv.alloc_outputs(B), nbuf=None if noise_mode == "none" else torch.zeros((B, sn.resolution, 2), **f64),
                   gen=torch.Generator(device=dev) if noise_mode == "seeded" else None, graph=None,
-                  sched=sn.make_schedule(B))                 # heaviest-first start order, from one sample to the next
+                  sched=sn.make_schedule(B))                 # order buffer: every scan ranks its robots and starts the heaviest first
         self._plan = pl
         return pl
 

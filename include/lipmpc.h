@@ -276,13 +276,13 @@ int lipmpc_lidar_sense_batch(int device, int64_t B, int32_t resolution, int32_t 
  *        eta = NaN where the geometry is degenerate (CoM on the hull boundary, zero-length hull edge)
  *  n_inferred [B], overflow [B] as lipmpc_lidar_sense_batch
  *  obs_xy / obs_nv: the rings as well, or both NULL;  hits, labels: or NULL
- *  schedule: NULL, or a device buffer of lipmpc_lidar_schedule_words(B) int32, ZEROED once by the caller and then handed to
- *        every launch of the same robots (a closed loop's samples).  A scan's length grows with its reading count (all-pairs
- *        clustering) and 4096 robots run in two rounds of waves, so a heavy robot started late sets the launch time; each
- *        launch leaves there its robots' reading counts and (one small extra kernel) the order -- heaviest first -- in
- *        which the next launch starts them: 0.16 instead of 0.24 ms per 4096 robots when the robots keep their weights.
- *        A pure scheduling hint: a buffer that holds no order for this B (first launch, another B) means index order, and
- *        every order gives the same results.  Launches sharing a schedule must be stream-ordered; it replays in a graph. */
+ *  schedule: NULL (the robots are scanned in index order), or a device buffer of lipmpc_lidar_schedule_words(B) int32, contents
+ *        arbitrary: scratch for the LAUNCH ORDER of this call.  A scan's length grows with its reading count (all-pairs
+ *        clustering) and 4096 robots run in two rounds of waves, so a heavy robot started late sets the launch time.  With
+ *        the buffer the call first ranks its robots -- one small kernel estimates every robot's reading count from the bounding
+ *        circles of the obstacles in range, a one-workgroup counting sort turns the estimates into an order, heaviest first --
+ *        and then starts the scans in that order (both included in the call: ~10 us per 4096 robots).  Nothing carries over
+ *        from one call to the next; every order gives the same results; calls sharing a buffer must be stream-ordered. */
 int lipmpc_lidar_c_eta_batch(int device, int64_t B, int32_t resolution, int32_t n_env, int32_t v_env,
                              int32_t env_shared, double lidar_range, double eps, int32_t min_samples,
                              int32_t n_obs_max, int32_t v_max, const double* state, const double* env_xy,

@@ -535,8 +535,8 @@ def test_gpu_constraint_assembly_fused_into_the_scan(golden_dir):
     for k in ("U", "X", "obj"):
         assert torch.equal(ref[k][ok], got[k][ok]), k
     assert int(ok.sum()) > 0.6 * B
-    # the heaviest-first schedule is a pure scheduling hint: first launch (empty schedule = index order), second launch
-    # (ordered by the first one's reading counts), a launch with another batch size in between -- same answers
+    # the launch order is a pure scheduling matter: with an order buffer the call ranks its robots itself (estimated reading
+    # counts, heaviest first) before it scans them -- same answers as in index order, launch after launch
     sched = sensor.make_schedule(B)
     for rep in range(3):
         got_s = sensor.sense(d_st, noise, c_eta=True, rings=False, schedule=sched)
@@ -545,7 +545,7 @@ def test_gpu_constraint_assembly_fused_into_the_scan(golden_dir):
         assert torch.equal(got_s["n_inferred"], lean["n_inferred"]) and torch.equal(got_s["overflow"], lean["overflow"])
         sc = sched.cpu().numpy()
         assert sc[0] == B and np.array_equal(np.sort(sc[2:2 + B]), np.arange(B))               # a complete order of the B robots ...
-        assert np.all(np.diff(sc[2 + B:][sc[2:2 + B]]) <= 0)                                   # ... by descending reading count
+        assert np.all(np.diff(sc[2 + B:][sc[2:2 + B]]) <= 0)                                   # ... by descending estimated reading count
     with pytest.raises(ValueError):
         sensor.sense(d_st[:100].contiguous(), noise[:100].contiguous(), c_eta=True, schedule=sched)
     # the whole step of the unknown-environment variant in one C call

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Dev tool: build a variant of liblipmpc.so with extra compiler flags into variants/<name>.so (only the objects given in INSTS
 # are rebuilt with the flags -- "16_5" = inst_16_5.o, "8:16_7" = the 8-variable inst8_16_7.o, "L:32_2" = the split-launch body
-# list_32_2.o, "api" = the C ABI object; the rest come from the normal build), for A/B timing on the GPU box through LIPMPC_LIB
+# list_32_2.o, "api" = the C ABI object, "lidar" = the LiDAR front end; the rest come from the normal build), for A/B timing on the GPU box through LIPMPC_LIB
 # (the shipped library is never replaced):
 #   tools/build_variant.sh phase "-DLIPMPC_PHASE_TIMING" "api 16_5 32_25 L:32_1 L:32_2 L:32_4"
 #   LIPMPC_LIB=$PWD/variants/phase.so LIPMPC_ALLOW_VARIANT=1 python tools/phase_cycles.py
@@ -18,6 +18,8 @@ if [ "$1" == "--check-all" ]; then
     first=${insts%% *}
     if [ "$first" == "api" ]; then
       hipcc $FLAGS $flags -c $C/lipmpc_api.hip -o /dev/null
+    elif [ "$first" == "lidar" ]; then
+      hipcc $FLAGS $flags -c $C/lipmpc_lidar.hip -o /dev/null
     else
       key=${first#*:}; g=${key%_*}; n=${key#*_}; extra=""; nv=$g
       [[ $first == L:* ]] && extra="-DINST_LIST"
@@ -35,10 +37,10 @@ for o in $C/build/*.o; do
   b=$(basename $o .o)
   use=$o
   for i in $insts; do
-    if [ "$i" == "api" ]; then
-      if [ "$b" == "api" ]; then
-        hipcc $FLAGS $flags -c $C/lipmpc_api.hip -o $C/build_$name/api.o
-        use=$C/build_$name/api.o
+    if [ "$i" == "api" ] || [ "$i" == "lidar" ]; then
+      if [ "$b" == "$i" ]; then
+        hipcc $FLAGS $flags -c $C/lipmpc_$i.hip -o $C/build_$name/$i.o
+        use=$C/build_$name/$i.o
       fi
       continue
     fi
