@@ -1,5 +1,6 @@
 """Dev tool: how much of the mixed-batch scan time is scheduling: the config-5 bench batch as it comes, sorted heaviest
-first / lightest first by reading count (plain launch), and on a schedule buffer (persistent launch)."""
+first / lightest first by TRUE reading count (plain launch), and ranked by the call itself (order buffer: estimated reading
+counts, lipmpc_lidar.hip: lidar_weight_kernel) -- with the correlation of that estimate with the true counts."""
 import sys, os, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import lipmpc
@@ -29,7 +30,11 @@ for name, idx in (("heaviest first", torch.argsort(npts, descending=True)), ("li
     s2, n2 = state[idx].contiguous(), noise[idx].contiguous()
     print("%-20s %.1f us" % (name, t(lambda: sensor.sense(s2, n2, out=sen, schedule=None))))
 sched = sensor.make_schedule(B)
-print("schedule buffer      %.1f us" % t(lambda: sensor.sense(state, noise, out=sen, schedule=sched)), sched[:16].cpu().tolist())
+print("ranked by the call   %.1f us" % t(lambda: sensor.sense(state, noise, out=sen, schedule=sched)), sched[:16].cpu().tolist())
+est = sched[2 + B:2 + 2 * B].double()
+top = set(torch.argsort(npts, descending=True)[: B // 10].tolist())
+print("estimate vs true reading counts: correlation %.3f; of the heaviest tenth, %d %% are in the estimate's heaviest fifth" % (
+    torch.corrcoef(torch.stack([est, npts.double()]))[0, 1].item(), 100 * len(top & set(torch.argsort(est, descending=True)[: B // 5].tolist())) // len(top)))
 light = torch.nonzero(npts < 144).flatten()[: (B // 2)]
 if len(light) >= 256:
     s3, n3 = state[light].contiguous(), noise[light].contiguous(); sen3 = sensor.alloc_outputs(len(light), rings=False, c_eta=True)
@@ -39,7 +44,3 @@ binid = (npts[:, None] < bins[None, :]).sum(1)                      # 0 = heavie
 idx = torch.argsort(binid, stable=True)
 s4, n4 = state[idx].contiguous(), noise[idx].contiguous()
 print("sorted by BIN only (plain launch)   %.1f us" % t(lambda: sensor.sense(s4, n4, out=sen, schedule=None)))
-idx = torch.argsort(npts, descending=True); s2, n2 = state[idx].contiguous(), noise[idx].contiguous()
-def pers_identity():
-    sched.zero_(); sensor.sense(s2, n2, out=sen, schedule=sched)
-print("heaviest first input + persistent launch in index order (schedule zeroed each time)  %.1f us (incl. the memset)" % t(pers_identity))
