@@ -89,7 +89,8 @@ class BatchedLipMpc:
     def set_workspace(self, capacity):
         """Split launch of this handle's step solves (lipmpc_set_workspace): for 32-lane problems (N > 8) in the exact mode
         the step runs as classification -> index lists -> one kernel per solver body (each with its own register
-        allocation), bit-identical results.  The handle sets one up by itself for the batch sizes it sees
+        allocation); same optimum, statuses and active sets as the single kernel (a problem may run in another body there:
+        last-bit differences).  The handle sets one up by itself for the batch sizes it sees
         (``auto_workspace``); 0 = back to the single dispatching kernel."""
         capacity = int(capacity)
         nbytes = int(self.lib.lipmpc_workspace_bytes(self._h, capacity)) if capacity > 0 else 0
@@ -113,9 +114,9 @@ class BatchedLipMpc:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h is not None and h.value:
+        if h is not None and h.value and C is not None:      # (C is None: interpreter shutdown)
             self.lib.lipmpc_destroy(h)
-            self._h = C.c_void_p()
+            self._h = None
 
     # ---- buffers --------------------------------------------------------------------------------
     def alloc_outputs(self, B, with_c_eta=False, with_diag=False, with_working=False):

@@ -86,6 +86,8 @@ def test_default_params_are_the_reference_config():
     # schedule buffer of the LiDAR front end: header + start order + reading counts (include/lipmpc.h)
     assert lib.lipmpc_lidar_schedule_words(4096) == 2 + 2 * 4096 and lib.lipmpc_lidar_schedule_words(0) == 2
     assert lib.lipmpc_lidar_schedule_words(-1) < 0
+    # split-launch workspace: argument errors without a handle
+    assert lib.lipmpc_workspace_bytes(C.c_void_p(0), 4096) < 0 and lib.lipmpc_set_workspace(C.c_void_p(0), C.c_void_p(0), 0) == -1
     # argument errors of the LiDAR entry points never reach a device (no GPU needed)
     z = C.c_void_p(0)
     assert lib.lipmpc_lidar_c_eta_batch(0, 1, 360, 0, 1, 1, C.c_double(1.5), C.c_double(0.3), 3, 12, 32, *([z] * 14)) == -1   # no c_eta

@@ -98,7 +98,8 @@ def test_every_instantiation_is_independent_of_leftover_state(N, n_obs):
 def test_every_solver_body_is_independent_of_leftover_state(N, n_obs):
     """The dispatching step kernel runs the 2-slot, the 7-slot or the handle's own solver body depending on how many obstacles
     keep a row: robots inside a ring of 0..n_obs small obstacles send waves to each of them, under the three register / LDS
-    fill patterns, with bit-identical outputs."""
+    fill patterns, with bit-identical outputs.  32-lane problems: both forms of the launch -- the split launch (classification,
+    binning, one kernel per body: what the handle runs by default) and the single dispatching kernel."""
     pz = _poison_lib()
     rng = np.random.default_rng(11 * N + n_obs)
     B = 128
@@ -116,17 +117,22 @@ def test_every_solver_body_is_independent_of_leftover_state(N, n_obs):
     goal = st[:, [0, 2]] + rng.uniform(-6, 6, (B, 2))
     args = (_dev(st, torch.float64), _dev(goal, torch.float64), _dev(foot, torch.int8), _dev(xy, torch.float64), _dev(nv, torch.int32), None)
     sv = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5))
-    outs = []
-    for pat in PATTERNS:
-        torch.cuda.synchronize()
-        assert pz.lipmpc_poison(pat, 15) == 0
-        o = sv.plan_step_batch(*args, with_diag=True)
-        torch.cuda.synchronize()
-        outs.append({k: v.cpu().numpy() for k, v in o.items()})
-    assert np.isin(outs[0]["status"], (0, 4)).mean() > 0.3
-    for o in outs[1:]:
-        for k in ("U", "X", "status", "iters", "active", "obj", "diag"):
-            assert np.array_equal(o[k], outs[0][k], equal_nan=True), (N, n_obs, k)
+    for split in ((True, False) if sv._split_capable else (False,)):
+        sv.auto_workspace = split
+        sv.set_workspace(B if split else 0)
+        outs = []
+        for pat in PATTERNS:
+            torch.cuda.synchronize()
+            assert pz.lipmpc_poison(pat, 15) == 0
+            o = sv.plan_step_batch(*args, with_diag=True, with_working=True)
+            torch.cuda.synchronize()
+            outs.append({k: v.cpu().numpy() for k, v in o.items()})
+        assert np.isin(outs[0]["status"], (0, 4)).mean() > 0.3
+        if split:
+            assert (sv._ws[:5] > 0).sum().item() >= 3               # the robots really spread over the bodies
+        for o in outs[1:]:
+            for k in ("U", "X", "status", "iters", "active", "working", "obj", "diag"):
+                assert np.array_equal(o[k], outs[0][k], equal_nan=True), (N, n_obs, split, k)
 
 
 def test_lidar_kernel_is_independent_of_leftover_state(golden_dir):
