@@ -452,3 +452,35 @@ def test_split_launch_against_the_single_kernel_and_the_oracle(N, n_obs):
     # handles that never split: 16 lanes per problem, or the modes that keep every row
     assert not lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=8, n_obs_max=10, v_max=5))._split_capable
     assert not lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=16, n_obs_max=10, v_max=5, flags=lipmpc.FLAG_INTERIOR))._split_capable
+
+
+def test_split_launch_replays_in_a_hip_graph():
+    """The split launch forks onto streams the handle owns and joins back by events on the caller's stream, so a captured
+    step (a closed loop's sample in a HIP graph, as UnknownEnvFleet does for the 16-lane steps) takes the side streams'
+    kernels along: capture one step of a 32-lane handle, replay it on new inputs, compare with the eager launch."""
+    from helpers import crowded_batch
+    N, n_obs, B = 12, 9, 600
+    st, goal, foot, xy, nv = crowded_batch(N, n_obs, B, seed=91)
+    args = [_dev(st, torch.float64), _dev(goal, torch.float64), _dev(foot, torch.int8), _dev(xy, torch.float64), _dev(nv, torch.int32)]
+    sv = lipmpc.BatchedLipMpc(lipmpc.LipMpcParams(N=N, n_obs_max=n_obs, v_max=5))
+    out = sv.alloc_outputs(B)
+    sv.plan_step_batch(*args, None, out=out)                      # warm-up outside the capture: workspace, streams, events
+    torch.cuda.synchronize()
+    assert sv._ws is not None
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            sv.plan_step_batch(*args, None, out=out)
+    st2 = st.copy(); st2[:, 0] += 0.03; st2[:, 2] -= 0.02
+    args[0].copy_(_dev(st2, torch.float64))                        # new states in the captured input buffer
+    for k in ("U", "status", "iters"):
+        out[k].zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    got = {k: out[k].clone() for k in ("U", "X", "status", "iters", "active", "obj")}
+    ref = sv.plan_step_batch(*args, None)
+    torch.cuda.synchronize()
+    assert int((ref["status"] == 0).sum()) > B // 3
+    for k, v in got.items():
+        assert torch.equal(torch.nan_to_num(v.double(), nan=7.0), torch.nan_to_num(ref[k].double(), nan=7.0)), k
