@@ -27,4 +27,5 @@ for (N,n_obs,B) in [(8,10,8192),(3,3,8192),(1,0,2048),(1,5,2048),(2,9,4096),(4,1
         ok=same&(gs==0); U=out["U"].cpu().numpy()
         du=np.abs(U[ok]-ref["U"][ok]).max() if ok.any() else 0
         nanbad=np.isnan(U[ok]).any()
-        print(f"N={N} n_obs={n_obs} B={B} flags={flags}: gpu {tg*1e3:.1f} ms | status gpu {np.bincount(gs,minlength=5).tolist()} oracle {np.bincount(ref['status'],minlength=5).tolist()} | mismatches {int((~same).sum())} | max dU {du:.2e} | max iters {int(out['iters'].max())} nan {nanbad}")
+        act_diff=int(np.any(out["active"].cpu().numpy().view(np.uint64)[ok]!=ref["active"][ok],axis=1).sum())     # tight sets, every certified problem
+        print(f"N={N} n_obs={n_obs} B={B} flags={flags}{' split' if getattr(sv,'_ws',None) is not None else ''}: gpu {tg*1e3:.1f} ms | status gpu {np.bincount(gs,minlength=5).tolist()} oracle {np.bincount(ref['status'],minlength=5).tolist()} | mismatches {int((~same).sum())} | max dU {du:.2e} | active (tight set) differs on {act_diff} of {int(ok.sum())} | max iters {int(out['iters'].max())} nan {nanbad}")
