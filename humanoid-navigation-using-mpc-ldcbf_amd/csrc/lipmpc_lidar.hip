@@ -27,6 +27,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "lipmpc_kernel.hpp"      // DPP row exchanges (lipmpc_dev::row_xor)
 
 namespace {
@@ -36,28 +38,64 @@ constexpr int WORDS = RMAX / 64;     // neighbour bit row
 constexpr int NO_ROOT = 0x7fffffff;
 constexpr int SOLO_MIN = 48;        // a cluster of at least this many points gets the whole wave in the hull stage
 constexpr int NCC = 64;             // candidates whose bounding circle is kept for the per-pass sector test
+constexpr int VFAST = 8;            // rings of at most this many vertices (v_env) are fetched in one round of loads
 constexpr int VSTAGE = 64;          // hull vertices staged per cluster (v_max <= VSTAGE)
 // order buffer (int32, scratch of ONE call): [B the order is valid for, -, order[B] (robot at launch position i), weight[B]]
 constexpr int SCHED_VALID = 0, SCHED_ORDER = 2;
 constexpr int NRUN = RMAX / 16;      // runs of 16 consecutive readings
-constexpr int ECAP = 2 * RMAX / 4;  // edges staged per chunk of the ray phase (4 doubles each, in the hull stage's point arrays)
-static_assert(4 * VSTAGE * 2 <= 2 * RMAX, "hull staging reuses the point arrays");
+constexpr int ECAP = 152;           // edges staged per chunk of the ray phase (5 doubles each, where the points go afterwards)
+static_assert(ECAP * 5 <= 2 * RMAX && ECAP % 2 == 0, "the staged edges live in the point array");
+static_assert(ECAP <= 65535 && RMAX <= 65535, "16-bit edge offsets and point indices");
 
 struct Cand { double x, y; int idx; };
+#ifdef LIPMPC_LIDAR_PHASES
+#define LIDAR_PHASE_END(n) if (dbg_stop == (n)) return
+#else
+#define LIDAR_PHASE_END(n)
+#endif
+#ifndef LIDAR_WAVES
+#define LIDAR_WAVES 4
+#endif
 
-
-// is candidate b a better "next hull vertex" than a when standing on p?  (b strictly to the right of p->a, or
-// collinear and farther; a.idx < 0 = no candidate yet; points equal to p are never candidates)
-__device__ __forceinline__ bool better(double px, double py, const Cand& a, const Cand& b) {
+// Is candidate b a better "next hull vertex" than a when standing on p?  (b strictly to the right of p->a, or collinear and
+// farther; a.idx < 0 = no candidate yet.)  Candidates are given as OFFSETS from p (a.x = x_a - p_x ...), formed once per step
+// instead of once per comparison.  Straight-line on purpose (the verdict assembled from masks): the march is a chain of
+// dependent steps, and the nest of divergent branches the short-circuit form compiles to cost more than the arithmetic it
+// skipped.  Exactly collinear pairs are rare enough for the tie-break to sit behind a wave-uniform branch.
+__device__ __forceinline__ bool better_from(const Cand& a, const Cand& b) {
 #pragma clang fp contract(off)
-  if (b.idx < 0) return false;
-  if (a.idx < 0) return true;
-  const double cr = (a.x - px) * (b.y - py) - (a.y - py) * (b.x - px);
-  if (cr < 0.0) return true;
-  if (cr > 0.0) return false;
-  const double da = (a.x - px) * (a.x - px) + (a.y - py) * (a.y - py);
-  const double db = (b.x - px) * (b.x - px) + (b.y - py) * (b.y - py);
-  return db > da || (db == da && b.idx < a.idx);
+  const double cr = a.x * b.y - a.y * b.x;
+  const bool both = (a.idx >= 0) & (b.idx >= 0);
+  bool tie = false;
+  if (__any(both & (cr == 0.0))) {
+    const double da = a.x * a.x + a.y * a.y;
+    const double db = b.x * b.x + b.y * b.y;
+    tie = (db > da) | ((db == da) & (b.idx < a.idx));
+  }
+  const bool geo = (cr < 0.0) | ((cr == 0.0) & tie);
+  return (b.idx >= 0) & ((a.idx < 0) | geo);
+}
+// the value lane l (wave-uniform) holds
+__device__ __forceinline__ double lane_value(double v, int l) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, l), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), l);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// the value held 16 / 32 lanes away, by v_permlane16_swap / v_permlane32_swap (VALU, no trip through the LDS crossbar)
+template <class T> __device__ __forceinline__ T wave_xor16(T v) { return lipmpc_dev::rowswap(v); }
+__device__ __forceinline__ unsigned wave_xor32_u(unsigned u) {
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);      // {lanes 0-31 everywhere, lanes 32-63 everywhere}
+  const unsigned lo = r[0], hi = r[1];
+  return (lipmpc_dev::fresh(threadIdx.x) & 32) ? lo : hi;
+}
+template <class T> __device__ __forceinline__ T wave_xor32(T v) {
+  if constexpr (sizeof(T) == 8) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = wave_xor32_u((unsigned)u), hi = wave_xor32_u((unsigned)(u >> 32));
+    return __builtin_bit_cast(T, ((unsigned long long)hi << 32) | lo);
+  } else {
+    return __builtin_bit_cast(T, wave_xor32_u(__builtin_bit_cast(unsigned, v)));
+  }
 }
 
 // closest point of one hull edge (a -> b) to p and the crossing test of the edge (prev -> a) with the +X ray from p:
@@ -82,28 +120,29 @@ __device__ __forceinline__ EdgeCp edge_closest(double pvx, double pvy, double ax
   return r;
 }
 
-__global__ __launch_bounds__(64) void lidar_sense_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LIDAR_WAVES, LIDAR_WAVES))) void lidar_sense_kernel(
     long B, int R, int n_env, int v_env, long env_stride, double lidar_range, double eps, int min_samples,
     int n_obs_max, int v_max, const double* __restrict__ state, const double* __restrict__ env_xy,
     const int32_t* __restrict__ env_nv, const double* __restrict__ ray_table, const double* __restrict__ noise,
     double* __restrict__ obs_xy, int32_t* __restrict__ obs_nv, double* __restrict__ c_eta, int32_t* __restrict__ n_inferred,
     int32_t* __restrict__ overflow, double* __restrict__ hits_out, int32_t* __restrict__ labels_out,
     int32_t* __restrict__ sched, int dbg_stop) {
-  __shared__ __attribute__((aligned(16))) double pxy_[2 * RMAX];
-  double* const px_ = pxy_;
-  double* const py_ = pxy_ + RMAX;
-  __shared__ __attribute__((aligned(16))) int comp_[RMAX];                    // -1 = no reading; core: component root; else NO_ROOT
-  __shared__ int root_[RMAX];                    // cluster root of every reading (NO_ROOT = noise)
-  __shared__ __attribute__((aligned(16))) double cxy_[2 * RMAX];   // ray phase: staged edges; hull stage: points in member-list order
-  double* const cx_ = cxy_;
-  double* const cy_ = cxy_ + RMAX;
-  double* const edge_ = cxy_;                    // [ECAP][4]: (b - a) and (robot - a) of every staged edge
-  __shared__ int roots_[64];
-  __shared__ int eoff_[65];                      // first staged edge of the chunk's candidates
-  __shared__ double candc_[NCC][3];              // bounding circle (centre, radius) of the first NCC candidate obstacles
-  __shared__ double bb16_[NRUN][4];              // bounding box (x0, x1, y0, y1) of each run of 16 points
-  __shared__ unsigned nearm_[NRUN];              // runs within eps of run a, as bits
-  __shared__ int cand_[RMAX];                    // obstacles that can be hit from here, list order
+  // LDS: 10.1 KB per wave = 16 waves per CU (the 160 KB of a CU are what caps this kernel's occupancy, not its registers:
+  // the scan is latency-bound, and went from 8 to 16 resident waves per CU with this layout).  One array of points, everything
+  // a lane owns of its own points (coordinates, cluster root) in registers, and the three small tables of the three phases on
+  // one another.
+  __shared__ __attribute__((aligned(16))) double pint_[2 * RMAX];   // ray phase: staged edges; then the readings (x, y), compacted in ray order
+  double* const edge_ = pint_;                   // [ECAP][4]: g = b - a and f = robot - a of every staged edge ...
+  double* const nua_ = pint_ + 4 * ECAP;         // [ECAP]:    ... and g x f, the ray-independent numerator of compute_intersection
+  __shared__ __attribute__((aligned(16))) int comp_[RMAX];          // -1 = no reading; core: component root; else NO_ROOT; hull stage: cluster offsets
+  __shared__ unsigned short cand_[RMAX];         // obstacles that can be hit from here, list order; then the ray of every reading; then member lists
+  __shared__ unsigned short eoff_[66];           // first staged edge of the chunk's candidates
+  __shared__ __attribute__((aligned(16))) double small_[NCC * 3];   // one phase's small table at a time:
+  double (*const candc_)[3] = reinterpret_cast<double (*)[3]>(small_);            // rays: bounding circle (centre, radius) of the first NCC candidates
+  double (*const bb16_)[4] = reinterpret_cast<double (*)[4]>(small_);             // neighbour rows: bounding box (x0, x1, y0, y1) of each run of 16 points
+  int* const roots_ = reinterpret_cast<int*>(small_);                             // components on: cluster roots, ascending [64]
+  unsigned short* const stagei_ = reinterpret_cast<unsigned short*>(small_ + 32); // hulls: [4][VSTAGE] vertices of the rings being marched, as point indices
+  static_assert(NRUN * 4 * 8 <= NCC * 3 * 8 && 32 * 8 + 4 * VSTAGE * 2 <= NCC * 3 * 8, "the small tables share one area");
 
   const int lane = threadIdx.x;
   if ((long)blockIdx.x >= B) return;
@@ -117,6 +156,16 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
     const long r = sched[SCHED_ORDER + blockIdx.x];
     if (r >= 0 && r < B) b = r;
   }
+#ifdef LIPMPC_LIDAR_PHASES
+  if (dbg_stop == 8) {            // placement probe (tools/lidar_placement.py): where the dispatcher put launch position blockIdx.x
+    if (lane == 0) {
+      n_inferred[blockIdx.x] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
+      overflow[blockIdx.x] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 20);       // HW_REG_XCC_ID
+    }
+    for (int i = 0; i < 16; ++i) __builtin_amdgcn_s_sleep(127);                     // stay resident while the grid is placed
+    return;
+  }
+#endif
   const double x0 = state[b * 5 + 0], y0 = state[b * 5 + 2];
   const double* exy = env_xy + b * env_stride * (long)n_env * v_env * 2;
   const int32_t* env = env_nv + b * env_stride * (long)n_env;
@@ -134,17 +183,31 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
       int nv = env[j];
       if (nv > v_env) { nv = v_env; in_ovf = 1; }
       const double* ring = exy + (long)j * v_env * 2;
-      for (int e = 0; e < nv; ++e) { mx += ring[2 * e]; my += ring[2 * e + 1]; }
+      double rad2 = 0.0;
+      if (v_env <= VFAST) {          // (wave-uniform) the whole ring in one round of loads: a loop of dependent loads is a loop of misses
+        double vx[VFAST], vy[VFAST];
+#pragma unroll
+        for (int e = 0; e < VFAST; ++e) { const int ee = e < nv ? e : 0; vx[e] = nv > 0 ? ring[2 * ee] : 0.0; vy[e] = nv > 0 ? ring[2 * ee + 1] : 0.0; }
+#pragma unroll
+        for (int e = 0; e < VFAST; ++e) if (e < nv) { mx += vx[e]; my += vy[e]; }
+        if (nv > 0) { mx /= nv; my /= nv; }
+#pragma unroll
+        for (int e = 0; e < VFAST; ++e) if (e < nv) rad2 = fmax(rad2, (vx[e] - mx) * (vx[e] - mx) + (vy[e] - my) * (vy[e] - my));
+      } else {
+        for (int e = 0; e < nv; ++e) { mx += ring[2 * e]; my += ring[2 * e + 1]; }
+        if (nv > 0) { mx /= nv; my /= nv; }
+        for (int e = 0; e < nv; ++e) rad2 = fmax(rad2, (ring[2 * e] - mx) * (ring[2 * e] - mx) + (ring[2 * e + 1] - my) * (ring[2 * e + 1] - my));
+      }
       if (nv > 0) {
-        mx /= nv; my /= nv;
-        for (int e = 0; e < nv; ++e) rad = fmax(rad, hypot(ring[2 * e] - mx, ring[2 * e + 1] - my));
-        keep = hypot(mx - x0, my - y0) <= (lidar_range + rad) * (1.0 + 1e-9) + 1e-9;
+        rad = sqrt(rad2) * (1.0 + 1e-12);                  // (any circle around the ring does: the margins below cover the rounding)
+        const double reach = (lidar_range + rad) * (1.0 + 1e-9) + 1e-9;
+        keep = (mx - x0) * (mx - x0) + (my - y0) * (my - y0) <= reach * reach;
       }
     }
     const unsigned long long ball = __ballot(keep);
     if (keep) {
       const int k = n_cand + __popcll(ball & ((1ull << lane) - 1ull));
-      if (k < RMAX) cand_[k] = j;
+      if (k < RMAX) cand_[k] = (unsigned short)j;
       if (k < NCC) { candc_[k][0] = mx; candc_[k][1] = my; candc_[k][2] = rad; }
     }
     n_cand += __popcll(ball);
@@ -154,9 +217,11 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
   if (n_cand > RMAX) { n_cand = RMAX; in_ovf = 1; }
   in_ovf = __any(in_ovf) ? 1 : 0;
   __syncthreads();
+  LIDAR_PHASE_END(6);
   // this lane's rays (i = lane + 64 p): direction b1 - a1, nearest hit so far.  A ray beyond the resolution has a zero
   // direction: every denominator is 0, it never hits.
-  double rdx[WORDS], rdy[WORDS], inv_len2[WORDS], bd[WORDS], hx[WORDS], hy[WORDS];
+  double rdx[WORDS], rdy[WORDS], bd[WORDS], hx[WORDS], hy[WORDS];
+  const double inv_len2 = 1.0 / (lidar_range * lidar_range);     // 1 / |ray|^2 for the sector test (an estimate with a margin)
 #pragma unroll
   for (int p = 0; p < WORDS; ++p) {
 #pragma clang fp contract(off)
@@ -164,7 +229,6 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
     const bool on = i < R;
     const double ex = x0 + lidar_range * (on ? ray_table[2 * i] : 0.0), ey = y0 + lidar_range * (on ? ray_table[2 * i + 1] : 0.0);
     rdx[p] = on ? ex - x0 : 0.0; rdy[p] = on ? ey - y0 : 0.0;
-    inv_len2[p] = __builtin_amdgcn_rcp(rdx[p] * rdx[p] + rdy[p] * rdy[p]);
     bd[p] = lidar_range; hx[p] = 0.0; hy[p] = 0.0;
   }
   // The candidates' edges go through LDS in chunks of at most 64 obstacles / ECAP edges (one chunk on ordinary maps):
@@ -186,18 +250,34 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
       const double* ring = exy + (long)j * v_env * 2;
       const int off = incl - nv;
       eoff_[lane] = off;
-      double ax = nv > 0 ? ring[0] : 0.0, ay = nv > 0 ? ring[1] : 0.0;
-      const double fx0 = ax, fy0 = ay;
-      for (int e = 0; e < nv; ++e) {
-        const bool last = e + 1 == nv;
-        const double bx = last ? fx0 : ring[2 * (e + 1)], by = last ? fy0 : ring[2 * (e + 1) + 1];
+      auto put_edge = [&](int e, double ax, double ay, double bx, double by) {
+#pragma clang fp contract(off)
         double* o = edge_ + 4 * (off + e);
-        o[0] = bx - ax; o[1] = by - ay; o[2] = x0 - ax; o[3] = y0 - ay;
-        ax = bx; ay = by;
+        const double gx = bx - ax, gy = by - ay, fx = x0 - ax, fy = y0 - ay;
+        o[0] = gx; o[1] = gy; o[2] = fx; o[3] = fy;
+        nua_[off + e] = gx * fy - gy * fx;
+      };
+      if (v_env <= VFAST) {
+        double vx[VFAST], vy[VFAST];
+#pragma unroll
+        for (int e = 0; e < VFAST; ++e) { const int ee = e < nv ? e : 0; vx[e] = nv > 0 ? ring[2 * ee] : 0.0; vy[e] = nv > 0 ? ring[2 * ee + 1] : 0.0; }
+#pragma unroll
+        for (int e = 0; e < VFAST; ++e)
+          if (e < nv) { const bool last = e + 1 == nv; put_edge(e, vx[e], vy[e], last ? vx[0] : vx[(e + 1) % VFAST], last ? vy[0] : vy[(e + 1) % VFAST]); }
+      } else {
+        double ax = nv > 0 ? ring[0] : 0.0, ay = nv > 0 ? ring[1] : 0.0;
+        const double fx0 = ax, fy0 = ay;
+        for (int e = 0; e < nv; ++e) {
+          const bool last = e + 1 == nv;
+          const double bx = last ? fx0 : ring[2 * (e + 1)], by = last ? fy0 : ring[2 * (e + 1) + 1];
+          put_edge(e, ax, ay, bx, by);
+          ax = bx; ay = by;
+        }
       }
       if (lane == nfit - 1) eoff_[nfit] = incl;
     } else if (lane == 0) { eoff_[0] = 0; eoff_[1] = 0; }      // (only when nothing fitted)
     __syncthreads();
+    LIDAR_PHASE_END(7);
     for (int c = 0; c < nfit; ++c) {
       const int e0 = eoff_[c], e1 = eoff_[c + 1];
       const int jc = jc0 + c;
@@ -210,7 +290,7 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
         // its bounding circle's centre to the ray segment > radius, with a margin far above the rounding of this
         // estimate) is skipped by the whole wave — its edges could not have produced a hit for any of these rays
         {
-          const double tt = fmin(1.0, fmax(0.0, (wx * rdx[p] + wy * rdy[p]) * inv_len2[p]));
+          const double tt = fmin(1.0, fmax(0.0, (wx * rdx[p] + wy * rdy[p]) * inv_len2));
           const double ddx = wx - tt * rdx[p], ddy = wy - tt * rdy[p];
           if (!__any(ddx * ddx + ddy * ddy <= cr2)) continue;
         }
@@ -218,8 +298,7 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
 #pragma clang fp contract(off)
           const double gx = edge_[4 * e], gy = edge_[4 * e + 1], fx = edge_[4 * e + 2], fy = edge_[4 * e + 3];
           const double denom = gy * rdx[p] - gx * rdy[p];
-          if (denom == 0.0) continue;
-          const double nua = gx * fy - gy * fx;
+          const double nua = nua_[e];
           const double nub = rdx[p] * fy - rdy[p] * fx;
           // 0 <= ua <= 1 and 0 <= ub <= 1 for ua = nua / denom, ub = nub / denom decided WITHOUT dividing: a correctly
           // rounded quotient is >= 0 exactly when the signs agree (or the numerator is +-0) and <= 1 exactly when
@@ -227,7 +306,7 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
           // the one unreachable exception: a negative quotient below 5e-324 in magnitude, which rounds to -0.0 >= 0).
           // Only a ray that really hits the edge pays for the division that places the hit.
           const double ad = fabs(denom), sa = (denom > 0.0) ? nua : -nua, sb = (denom > 0.0) ? nub : -nub;
-          if (sa >= 0.0 && sa <= ad && sb >= 0.0 && sb <= ad) {
+          if ((denom != 0.0) & (sa >= 0.0) & (sa <= ad) & (sb >= 0.0) & (sb <= ad)) {
             const double ua = nua / denom;
             const double qx = x0 + ua * rdx[p], qy = y0 + ua * rdy[p];
             const double dd = sqrt((qx - x0) * (qx - x0) + (qy - y0) * (qy - y0));
@@ -240,6 +319,11 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
     jc0 += nfit;
   }
   in_ovf = __any(in_ovf) ? 1 : 0;
+  // Readings (hit + noise) go from the registers straight into the list compacted in ray order (typically 110-200 of 360 rays
+  // return one): clustering and hulls then sweep n points instead of RMAX slots.  Order is preserved, so "smallest core index"
+  // numbering, border-point assignment and every index tie-break are those of the uncompacted scan.  (The staged edges are
+  // dead: the ray loop ends on a barrier.)
+  int n_pts = 0;
 #pragma unroll
   for (int p = 0; p < WORDS; ++p) {
 #pragma clang fp contract(off)
@@ -247,42 +331,21 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
     const bool have = bd[p] < lidar_range;           // bd starts at the range and only ever gets strictly smaller
     double qx = have ? hx[p] : 0.0, qy = have ? hy[p] : 0.0;
     if (have && noise) { qx = qx + noise[(b * R + i) * 2]; qy = qy + noise[(b * R + i) * 2 + 1]; }
-    px_[i] = qx; py_[i] = qy;
-    comp_[i] = have ? NO_ROOT : -1;
     if (hits_out && i < R) { hits_out[(b * R + i) * 2] = have ? qx : NAN; hits_out[(b * R + i) * 2 + 1] = have ? qy : NAN; }
+    const unsigned long long ball = __ballot(have);
+    if (have) {
+      const int k = n_pts + __popcll(ball & ((1ull << lane) - 1ull));
+      pint_[2 * k] = qx; pint_[2 * k + 1] = qy; cand_[k] = (unsigned short)i;      // cand_ is free after the ray casting: ray of point k
+    }
+    n_pts += __popcll(ball);
   }
   __syncthreads();
 
-#ifdef LIPMPC_LIDAR_PHASES
-#define LIDAR_PHASE_END(n) if (dbg_stop == (n)) return
-#else
-#define LIDAR_PHASE_END(n)
-#endif
   LIDAR_PHASE_END(1);
   // ---- 2. DBSCAN ------------------------------------------------------------------------------------
-  // Readings are first compacted in ray order (typically 110-200 of 360 rays return one): clustering and hulls then
-  // sweep n points instead of RMAX slots.  Order is preserved, so "smallest core index" numbering, border-point
-  // assignment and every index tie-break are those of the uncompacted scan.  In place: slot k <= i always, one
-  // word of 64 rays is read by the whole wave before its survivors are written back.
-  int n_pts = 0;
-  for (int w = 0; w < WORDS; ++w) {
-    const int i = w * 64 + lane;
-    const bool have = comp_[i] >= 0;
-    const double hx = px_[i], hy = py_[i];
-    const unsigned long long ball = __ballot(have);
-    __syncthreads();
-    if (have) {
-      const int k = n_pts + __popcll(ball & ((1ull << lane) - 1ull));
-      px_[k] = hx; py_[k] = hy; cand_[k] = i;               // cand_ is free after the ray casting: ray of point k
-    }
-    n_pts += __popcll(ball);
-    __syncthreads();
-  }
   const int NW = (n_pts + 63) >> 6;                      // words / passes actually in use (wave-uniform)
   const int npad = NW << 6;
-  for (int i = lane; i < RMAX; i += 64) comp_[i] = (i < n_pts) ? NO_ROOT : -1;
   if (labels_out) for (int i = lane; i < R; i += 64) labels_out[b * R + i] = -2;      // -2 = no reading
-  __syncthreads();
   const double eps2 = eps * eps;
   unsigned long long vmask[WORDS];                  // which points exist
 #pragma unroll
@@ -291,32 +354,29 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
     vmask[w] = left >= 64 ? ~0ull : (left <= 0 ? 0ull : ((1ull << left) - 1ull));
   }
   // row[k][w]: neighbour bits of point lane + 64 k against the 64 points of word w — kept in registers (the lane
-  // that owns a point is the only one that reads its row), which keeps the LDS footprint at 20 KB = 8 waves per CU.
+  // that owns a point is the only one that reads its row).
   // All-pairs is 147 k distance tests for 384 readings (it was the longest phase of the scan), so the sweep is pruned
   // and each test made cheap:
   //  * readings come in ray order, so a RUN of 16 consecutive points is a short piece of one obstacle's outline with a
-  //    small bounding box.  Run a is tested against word w only if its box comes within eps of the box of one of w's
-  //    four runs (a 24 x 24 bit matrix of run pairs, one lane per run, computed once); both box tests are conservative
-  //    (eps with a margin far above any rounding), so no neighbour pair is ever dropped;
-  //  * a visited (run, word) tile is computed COLUMN by column: every lane holds one point of word w in registers, the
-  //    run's point kk comes as one LDS broadcast read, one compare gives the 64 bits "points of word w within eps of
-  //    point kk" as a wave mask -- by symmetry row[k][w] of point kk -- and v_writelane drops it into lane kk:
-  //    8 VALU instructions per 64 pair tests, no bit insertion.  dx^2 + dy^2 does not depend on which of the two
-  //    points is subtracted from which, so the bits are those of the reference's distance test.
+  //    small bounding box.  Word k is tested against run a of word w only if the run's box comes within eps of the box of one
+  //    of k's four runs (a 24 x 24 bit matrix of run pairs, one lane per run, computed once); both box tests are conservative
+  //    (eps with a margin far above any rounding), so no neighbour pair is ever dropped; and a pair of runs whose boxes lie
+  //    within eps of each other corner to corner (a dense stretch of wall; a robot hemmed in) is all ones without a test;
+  //  * a visited (word, run) tile is computed column by column: every lane holds its point of word k in registers, the
+  //    run's point comes as one LDS broadcast read, and the compare's result goes into the lane's row word through the
+  //    carry of an add (7 VALU instructions per 64 pair tests, nothing scalar in the chain).
   unsigned long long row[WORDS][WORDS];
-  double wxr[WORDS], wyr[WORDS];                         // this lane's point of every word
-  double* const pint_ = cxy_;                            // [RMAX][2] interleaved copy of the points (the staged edges are dead)
 #pragma unroll
   for (int k = 0; k < WORDS; ++k) {
-    wxr[k] = px_[k * 64 + lane]; wyr[k] = py_[k * 64 + lane];
-    pint_[2 * (k * 64 + lane)] = wxr[k]; pint_[2 * (k * 64 + lane) + 1] = wyr[k];
 #pragma unroll
     for (int w = 0; w < WORDS; ++w) row[k][w] = 0ull;
   }
 #pragma unroll
   for (int w = 0; w < WORDS; ++w) {                       // boxes of the runs (empty run: an empty box)
+    if (w >= NW) continue;
     const bool vi = (vmask[w] >> lane) & 1ull;
-    double x0 = vi ? wxr[w] : INFINITY, x1 = vi ? wxr[w] : -INFINITY, y0 = vi ? wyr[w] : INFINITY, y1 = vi ? wyr[w] : -INFINITY;
+    const double wx = pint_[2 * (w * 64 + lane)], wy = pint_[2 * (w * 64 + lane) + 1];     // (slots past n_pts: never used)
+    double x0 = vi ? wx : INFINITY, x1 = vi ? wx : -INFINITY, y0 = vi ? wy : INFINITY, y1 = vi ? wy : -INFINITY;
     x0 = fmin(x0, lipmpc_dev::row_xor<1>(x0)); x1 = fmax(x1, lipmpc_dev::row_xor<1>(x1)); y0 = fmin(y0, lipmpc_dev::row_xor<1>(y0)); y1 = fmax(y1, lipmpc_dev::row_xor<1>(y1));
     x0 = fmin(x0, lipmpc_dev::row_xor<2>(x0)); x1 = fmax(x1, lipmpc_dev::row_xor<2>(x1)); y0 = fmin(y0, lipmpc_dev::row_xor<2>(y0)); y1 = fmax(y1, lipmpc_dev::row_xor<2>(y1));
     x0 = fmin(x0, lipmpc_dev::row_xor<4>(x0)); x1 = fmax(x1, lipmpc_dev::row_xor<4>(x1)); y0 = fmin(y0, lipmpc_dev::row_xor<4>(y0)); y1 = fmax(y1, lipmpc_dev::row_xor<4>(y1));
@@ -325,84 +385,77 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
   }
   __syncthreads();
   const double epsx = eps * (1.0 + 1e-6) + 1e-9;         // eps with a margin for the box tests
-  {   // run a = lane: which runs b come within eps of it (bit b)
-    unsigned nm = 0u;
+  // run a = lane: which runs b come within eps of it (bit b of nm: some pair may be neighbours), and which lie within eps of it
+  // as a whole (bit b of fm: EVERY pair is -- the farthest corners of the two boxes pass the distance test itself, same
+  // operations in the same order, and rounding is monotone, so every pair of points passes it too: no margin needed)
+  unsigned nm = 0u, fm = 0u;
+  {
+#pragma clang fp contract(off)
     const double* me = bb16_[lane < NRUN ? lane : 0];
-    const double ax0 = me[0] - epsx, ax1 = me[1] + epsx, ay0 = me[2] - epsx, ay1 = me[3] + epsx;
+    const double mx0 = me[0], mx1 = me[1], my0 = me[2], my1 = me[3];
+    const double ax0 = mx0 - epsx, ax1 = mx1 + epsx, ay0 = my0 - epsx, ay1 = my1 + epsx;
 #pragma unroll 4
-    for (int rb = 0; rb < NRUN; ++rb) {
+    for (int rb = 0; rb < 4 * NW; ++rb) {                 // (the runs of the words in use)
       const double* o = bb16_[rb];
-      if (o[0] <= ax1 && o[1] >= ax0 && o[2] <= ay1 && o[3] >= ay0) nm |= 1u << rb;
+      const double ox0 = o[0], ox1 = o[1], oy0 = o[2], oy1 = o[3];
+      if ((ox0 <= ax1) & (ox1 >= ax0) & (oy0 <= ay1) & (oy1 >= ay0)) nm |= 1u << rb;
+      const double dxm = fmax(fabs(mx1 - ox0), fabs(ox1 - mx0)), dym = fmax(fabs(my1 - oy0), fabs(oy1 - my0));
+      if (dxm * dxm + dym * dym <= eps2) fm |= 1u << rb;
     }
-    if (lane < NRUN) nearm_[lane] = nm;
   }
-  __syncthreads();
-  // (lo, hi) with lane l (wave-uniform) replaced by the wave-uniform 64-bit mask.  v_writelane_b32 takes ONE scalar
-  // operand besides m0 (constant bus), so the lane select goes through m0, saved and restored around the pair.
-  auto wrlane64 = [](int& lo, int& hi, unsigned long long mask, int l) {
-    int keep;
-    asm("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\ts_mov_b32 m0, %2"
-        : "+v"(lo), "+v"(hi), "=&s"(keep)
-        : "s"((int)(unsigned)mask), "s"((int)(unsigned)(mask >> 32)), "s"(l));
+  // One block of the matrix = the lane's point of word k against the 64 points of word w, 16 columns (one run) at a time,
+  // highest column first: the bit goes in through the carry, bits = 2 bits + (d2 <= eps2).
+  auto shift_in = [&](unsigned& bits, double d2) {
+    asm("v_cmp_ge_f64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "s"(eps2), "v"(d2) : "vcc");
   };
-  // Only the blocks w >= k are computed: in a block with w > k every lane also notes, per column, whether ITS point (of
-  // word w) is within eps of the column's point (of word k) -- bit kk of its own row[w][k], the transposed block, for
-  // two more instructions per column instead of a second pass.
   for (int k = 0; k < NW; ++k) {                          // wave-uniform
-    unsigned nmk[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) nmk[a] = __builtin_amdgcn_readfirstlane(nearm_[k * 4 + a]);
+    const double mx = pint_[2 * (k * 64 + lane)], my = pint_[2 * (k * 64 + lane) + 1];      // this lane's point of word k
     const int leftk = n_pts - k * 64;
-    const unsigned long long vmk = leftk >= 64 ? ~0ull : ((1ull << leftk) - 1ull);        // vmask[k] (leftk >= 1 for k < NW)
-    const bool own_k = (vmk >> lane) & 1ull;
+    const bool own_k = lane < leftk;                      // ... exists
 #pragma unroll
     for (int w = 0; w < WORDS; ++w) {
-      if (w >= NW || w < k) continue;
-      const bool off = w != k;                            // wave-uniform: an off-diagonal block also fills its transpose
-      int lo = 0, hi = 0;                                 // the row words being assembled: lane kk gets the mask of column kk
-      unsigned tlo = 0u, thi = 0u;                        // this lane's point (word w) against the columns (word k)
+      if (w >= NW) continue;
+      unsigned piece[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        if (((nmk[a] >> (4 * w)) & 0xFu) == 0u) continue; // run a of word k has no point near word w
-        const double* col = pint_ + 2 * (k * 64 + a * 16);
+        piece[a] = 0u;
+        const unsigned nk = (__builtin_amdgcn_readlane(nm, w * 4 + a) >> (4 * k)) & 0xFu;
+        const unsigned fk = (__builtin_amdgcn_readlane(fm, w * 4 + a) >> (4 * k)) & 0xFu;
+        if (nk == 0u) continue;                           // run a of word w has no point near word k
+        if (nk == fk) {                                   // ... or each run of word k has all of it or none of it within eps
+          piece[a] = ((fk >> (lane >> 4)) & 1u) ? 0xFFFFu : 0u;
+          continue;
+        }
+        const double* col = pint_ + 2 * (w * 64 + a * 16);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u4 = 3; u4 >= 0; --u4) {                 // four columns' distances, then their four bits
 #pragma clang fp contract(off)
-          const double dx = wxr[w] - col[2 * u], dy = wyr[w] - col[2 * u + 1];
-          const bool near = dx * dx + dy * dy <= eps2;
-          const unsigned long long mask = __ballot(near);
-          wrlane64(lo, hi, mask, a * 16 + u);
-          if (off) {
-            constexpr unsigned one = 1u;
-            if (a < 2) tlo |= near ? (one << ((a * 16 + u) & 31)) : 0u;
-            else thi |= near ? (one << ((a * 16 + u) & 31)) : 0u;
-          }
-        }
-      }
-      const unsigned long long bits = ((((unsigned long long)(unsigned)hi) << 32) | (unsigned)lo) & vmask[w];
-      const unsigned long long tbits = ((((unsigned long long)thi) << 32) | tlo) & vmk;
-      const bool own_w = (vmask[w] >> lane) & 1ull;
+          double d2[4];
 #pragma unroll
-      for (int k2 = 0; k2 < WORDS; ++k2) {
-        if (k2 == k) {                                     // k is wave-uniform
-          row[k2][w] = own_k ? bits : 0ull;
-          if (off) row[w][k2] = own_w ? tbits : 0ull;
+          for (int j = 0; j < 4; ++j) {
+            const double dx = mx - col[2 * (4 * u4 + j)], dy = my - col[2 * (4 * u4 + j) + 1];
+            d2[j] = dx * dx + dy * dy;
+          }
+#pragma unroll
+          for (int j = 3; j >= 0; --j) shift_in(piece[a], d2[j]);
         }
+        __builtin_amdgcn_sched_barrier(0);                // (one run's loads in flight at a time: the scheduler would hoist them all)
       }
+      const unsigned lo = piece[0] | (piece[1] << 16), hi = piece[2] | (piece[3] << 16);
+      const unsigned long long bits = own_k ? (((((unsigned long long)hi) << 32) | lo) & vmask[w]) : 0ull;
+#pragma unroll
+      for (int k2 = 0; k2 < WORDS; ++k2) if (k2 == k) row[k2][w] = bits;
     }
   }
   // core points (>= min_samples neighbours, the point itself included) start as their own root
 #pragma unroll
   for (int k = 0; k < WORDS; ++k) {
-    if (k >= NW) continue;
     const int i = k * 64 + lane;
     int cnt = 0;
 #pragma unroll
     for (int w = 0; w < WORDS; ++w) cnt += __popcll(row[k][w]);
-    root_[i] = (comp_[i] >= 0 && cnt >= min_samples) ? i : NO_ROOT;
+    comp_[i] = (i < n_pts) ? ((cnt >= min_samples) ? i : NO_ROOT) : -1;
   }
-  __syncthreads();
-  for (int i = lane; i < npad; i += 64) if (comp_[i] >= 0) comp_[i] = root_[i];
   __syncthreads();
   LIDAR_PHASE_END(2);
   // Connected components of the core points, label = smallest core index of the component.
@@ -487,15 +540,14 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
     flatten();
   }
   LIDAR_PHASE_END(4);
-  // cluster root of every reading: own component for cores, smallest neighbouring core component for the rest
+  // cluster root of every reading (of this lane's point of every word: nobody else asks for it): own component for cores,
+  // smallest neighbouring core component for the rest
+  int rootr[WORDS];
 #pragma unroll
   for (int k = 0; k < WORDS; ++k) {
-    if (k >= NW) continue;
-    const int i = k * 64 + lane;
-    const int ci = comp_[i];
-    root_[i] = (ci < 0) ? NO_ROOT : ((ci != NO_ROOT) ? ci : touch[k]);
+    const int ci = (k < NW) ? comp_[k * 64 + lane] : -1;
+    rootr[k] = (ci < 0) ? NO_ROOT : ((ci != NO_ROOT) ? ci : touch[k]);
   }
-  __syncthreads();
   LIDAR_PHASE_END(5);
   // roots in ascending order = cluster labels 0, 1, ...
   int n_clusters = 0;
@@ -511,9 +563,12 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
   }
   __syncthreads();
   if (labels_out) {
-    for (int i = lane; i < n_pts; i += 64) {
+#pragma unroll
+    for (int w = 0; w < WORDS; ++w) {
+      const int i = w * 64 + lane;
+      if (i >= n_pts) continue;
       int lab = -1;                                           // -1 noise
-      const int r = root_[i];
+      const int r = rootr[w];
       if (r != NO_ROOT) for (int k = 0; k < n_clusters && k < 64; ++k) if (roots_[k] == r) lab = k;
       labels_out[b * R + cand_[i]] = lab;
     }
@@ -531,23 +586,20 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
   if (onv) for (int k = lane; k < n_obs_max; k += 64) onv[k] = 0;
   if (oce) for (int k = lane; k < n_obs_max * 4; k += 64) oce[k] = 0.0;       // eta = (0, 0): empty slot
   const int nc = n_clusters < 64 ? n_clusters : 64;
-  int* list_ = cand_;                                   // member lists, cluster after cluster (labels are written)
+  unsigned short* list_ = cand_;                        // member lists, cluster after cluster (labels are written)
   int* coff_ = comp_;                                   // coff_[k] .. coff_[k+1]: members of cluster k
-  double* stage_ = pxy_;                                // [4][VSTAGE][2]: the points live on in cx_/cy_ from here
   __syncthreads();
   {
     int off = 0;
     for (int k = 0; k < nc; ++k) {
       const int r = roots_[k];
       if (lane == 0) coff_[k] = off;
-      for (int w = 0; w < NW; ++w) {
-        const int i = w * 64 + lane;
-        const bool m = root_[i] == r;
+#pragma unroll
+      for (int w = 0; w < WORDS; ++w) {
+        if (w >= NW) continue;
+        const bool m = rootr[w] == r;
         const unsigned long long ball = __ballot(m);
-        if (m) {
-          const int pos = off + __popcll(ball & ((1ull << lane) - 1ull));
-          list_[pos] = i; cx_[pos] = px_[i]; cy_[pos] = py_[i];
-        }
+        if (m) list_[off + __popcll(ball & ((1ull << lane) - 1ull))] = (unsigned short)(w * 64 + lane);
         off += __popcll(ball);
       }
     }
@@ -563,66 +615,119 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
   };
   auto wave_best = [&](Cand& c, auto&& take_other) {    // all 64 lanes: in-row DPP butterfly, then two cross-row steps
     row_best(c, take_other);
-    { Cand o; o.x = __shfl_xor(c.x, 16, 64); o.y = __shfl_xor(c.y, 16, 64); o.idx = __shfl_xor(c.idx, 16, 64); if (take_other(c, o)) c = o; }
-    { Cand o; o.x = __shfl_xor(c.x, 32, 64); o.y = __shfl_xor(c.y, 32, 64); o.idx = __shfl_xor(c.idx, 32, 64); if (take_other(c, o)) c = o; }
+    { Cand o; o.x = wave_xor16(c.x); o.y = wave_xor16(c.y); o.idx = wave_xor16(c.idx); if (take_other(c, o)) c = o; }
+    { Cand o; o.x = wave_xor32(c.x); o.y = wave_xor32(c.y); o.idx = wave_xor32(c.idx); if (take_other(c, o)) c = o; }
   };
-  // Clusters are processed in order.  A large cluster (a wall seen over many rays) gets the whole wave — its member
-  // scan is what a march step costs —, consecutive small ones share a wave, one per 16-lane row.
+  auto lex = [](const Cand& a, const Cand& o) {
+    return (o.idx >= 0) & ((a.idx < 0) | (o.x < a.x) | ((o.x == a.x) & ((o.y < a.y) | ((o.y == a.y) & (o.idx < a.idx)))));
+  };
+  // One group of clusters: a lane fetches ITS members of its cluster once (point index from the member list, coordinates from
+  // the point array: at most NJ of them) and every step of the march runs on registers and DPP alone -- the march is a chain
+  // of dependent steps, and an LDS round trip per candidate and step was most of what a step cost.
+  auto march_group = [&](auto nj_c, auto solo_c, int g, int ng) -> int {
+    constexpr int NJ = decltype(nj_c)::value;
+    constexpr bool SOLO = decltype(solo_c)::value;
+    constexpr int W = SOLO ? 64 : 16;
+    const int lw = SOLO ? lane : l16, qrow = SOLO ? 0 : q;
+    const int k = g + qrow;
+    const bool on = qrow < ng;
+    const int beg = on ? coff_[k] : 0, end = on ? coff_[k + 1] : 0;
+    Cand c[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int t = beg + lw + j * W;
+      const bool have = t < end;
+      const int i = have ? (int)list_[t] : 0;
+      c[j].x = pint_[2 * i]; c[j].y = pint_[2 * i + 1]; c[j].idx = have ? i : -1;
+    }
+    // lexicographically smallest point of the cluster
+    Cand st; st.idx = -1; st.x = 0.0; st.y = 0.0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) if (lex(st, c[j])) st = c[j];
+    if (SOLO) wave_best(st, lex); else row_best(st, lex);
+    // Jarvis march (of the rows in lock step)
+    double cxp = st.x, cyp = st.y;
+    int cip = st.idx;
+    int nvert = 0;
+    bool done = !on;
+    float ux = 0.0f, uy = -1.0f;       // the direction the march arrived along (the start is the lowest of the leftmost points)
+    for (int step = 0; step <= v_max; ++step) {
+      if (__all(done)) break;
+      if (!done && nvert < VSTAGE && lw == 0) stagei_[qrow * VSTAGE + nvert] = (unsigned short)cip;
+      if (!done) ++nvert;
+      // the candidates as seen from the vertex the march stands on (points equal to it are never candidates): the offsets
+      // are what every comparison of this step works on, and they are what travels through the reduction
+      // The winner is first GUESSED: the candidate with the smallest turn from the edge the march came along, by a
+      // single-precision key (s / (|s| + |t|), s and t the dot and cross product of that edge with the offset: decreasing in the
+      // angle over [0, pi]) -- a reduction over two words per lane instead of five with a predicate at every stage -- and then
+      // PROVED: no candidate of any lane beats it under the exact predicate.  The predicate is a strict total order with one
+      // maximum, so a guess that passes IS the exact reduction's result; one that fails (candidates closer in angle than single
+      // precision resolves, exact collinearity, duplicates) sends the wave through the exact reduction.
+      Cand r[NJ];
+      float key = -INFINITY;
+      int kidx = -1;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+#pragma clang fp contract(off)
+        r[j].x = c[j].x - cxp; r[j].y = c[j].y - cyp;
+        r[j].idx = ((r[j].x == 0.0) & (r[j].y == 0.0)) ? -1 : c[j].idx;
+        const float fx = (float)r[j].x, fy = (float)r[j].y;
+        const float sdot = ux * fx + uy * fy, tcr = ux * fy - uy * fx;
+        const float kj = r[j].idx < 0 ? -INFINITY : sdot * __builtin_amdgcn_rcpf(fabsf(sdot) + fabsf(tcr) + 1e-37f);
+        if (kj > key) { key = kj; kidx = r[j].idx; }
+      }
+      auto key_step = [&](float ok, int oi) { const bool take = ok > key; key = take ? ok : key; kidx = take ? oi : kidx; };
+      key_step(lipmpc_dev::row_xor<1>(key), lipmpc_dev::row_xor<1>(kidx));
+      key_step(lipmpc_dev::row_xor<2>(key), lipmpc_dev::row_xor<2>(kidx));
+      key_step(lipmpc_dev::row_xor<4>(key), lipmpc_dev::row_xor<4>(kidx));
+      key_step(lipmpc_dev::row_xor<8>(key), lipmpc_dev::row_xor<8>(kidx));
+      if (SOLO) { key_step(wave_xor16(key), wave_xor16(kidx)); key_step(wave_xor32(key), wave_xor32(kidx)); }
+      // (lanes of a row may hold different guesses when keys tie: lane 0's is the row's)
+      kidx = SOLO ? __builtin_amdgcn_readfirstlane(kidx) : lipmpc_dev::dpp0<0x150>(kidx);       // row_newbcast:0
+      Cand best;
+      {
+#pragma clang fp contract(off)
+        const int gi = kidx < 0 ? 0 : kidx;
+        best.x = pint_[2 * gi] - cxp; best.y = pint_[2 * gi + 1] - cyp; best.idx = kidx;
+        if (kidx < 0) { best.x = 0.0; best.y = 0.0; }
+      }
+      bool beaten = false;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) beaten |= better_from(best, r[j]);
+      if (__any(beaten)) {                                               // the exact reduction
+        best.idx = -1; best.x = 0.0; best.y = 0.0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) if (better_from(best, r[j])) best = r[j];
+        auto right = [&](const Cand& a, const Cand& o) { return better_from(a, o); };
+        if (SOLO) wave_best(best, right); else row_best(best, right);
+      }
+      const int bi = best.idx < 0 ? 0 : best.idx;
+      const double bx = pint_[2 * bi], by = pint_[2 * bi + 1];           // where the winner is
+      if (!done) {
+        if (best.idx < 0) done = true;                                   // single (repeated) point
+        else if (bx == st.x && by == st.y) done = true;                  // ring closed
+        else { cxp = bx; cyp = by; cip = best.idx; ux = (float)best.x; uy = (float)best.y; }
+      }
+    }
+    return nvert;
+  };
+  // Clusters are processed in order.  A large cluster (a wall seen over many rays) gets the whole wave, consecutive small
+  // ones share a wave, one per 16-lane row.
   for (int g = 0; g < nc;) {
     const bool solo = coff_[g + 1] - coff_[g] >= SOLO_MIN;            // wave-uniform
     int ng = 1;
     if (!solo) while (ng < 4 && g + ng < nc && coff_[g + ng + 1] - coff_[g + ng] < SOLO_MIN) ++ng;
-    const int W = solo ? 64 : 16;
-    const int lw = solo ? lane : l16, qrow = solo ? 0 : q;
-    const int k = g + qrow;
-    const bool on = qrow < ng;
-    const int beg = on ? coff_[k] : 0, end = on ? coff_[k + 1] : 0;
-    // lexicographically smallest point of the cluster
-    Cand st; st.idx = -1; st.x = 0.0; st.y = 0.0;
-    for (int t = beg + lw; t < end; t += W) {
-      const int i = list_[t];
-      const double x = cx_[t], y = cy_[t];
-      if (st.idx < 0 || x < st.x || (x == st.x && (y < st.y || (y == st.y && i < st.idx)))) { st.x = x; st.y = y; st.idx = i; }
-    }
-    auto lex = [](const Cand& a, const Cand& o) {
-      return o.idx >= 0 && (a.idx < 0 || o.x < a.x || (o.x == a.x && (o.y < a.y || (o.y == a.y && o.idx < a.idx))));
-    };
-    if (solo) wave_best(st, lex); else row_best(st, lex);
-    // Jarvis march (of the rows in lock step)
-    double cxp = st.x, cyp = st.y;
-    int nvert = 0;
-    bool done = !on;
-    for (int step = 0; step <= v_max; ++step) {
-      if (__all(done)) break;
-      if (!done && nvert < VSTAGE && lw == 0) { stage_[(qrow * VSTAGE + nvert) * 2] = cxp; stage_[(qrow * VSTAGE + nvert) * 2 + 1] = cyp; }
-      if (!done) ++nvert;
-      Cand best; best.idx = -1; best.x = 0.0; best.y = 0.0;
-      for (int t = beg + lw; t < end; t += 2 * W) {               // two independent candidates per trip
-        const int t2 = t + W;
-        const bool two = t2 < end;
-        Cand c1, c2;
-        c1.x = cx_[t]; c1.y = cy_[t]; c1.idx = list_[t];
-        c2.x = cx_[two ? t2 : t]; c2.y = cy_[two ? t2 : t]; c2.idx = two ? list_[t2] : -1;
-        if (!(c1.x == cxp && c1.y == cyp) && better(cxp, cyp, best, c1)) best = c1;
-        if (two && !(c2.x == cxp && c2.y == cyp) && better(cxp, cyp, best, c2)) best = c2;
-      }
-      auto right = [&](const Cand& a, const Cand& o) { return better(cxp, cyp, a, o); };
-      if (solo) wave_best(best, right); else row_best(best, right);
-      if (!done) {
-        if (best.idx < 0) done = true;                                   // single (repeated) point
-        else if (best.x == st.x && best.y == st.y) done = true;          // ring closed
-        else { cxp = best.x; cyp = best.y; }
-      }
-    }
+    const int nvert = solo ? march_group(std::integral_constant<int, WORDS>{}, std::true_type{}, g, 1)
+                           : march_group(std::integral_constant<int, (SOLO_MIN + 14) / 16>{}, std::false_type{}, g, ng);
     __syncthreads();
     // < 3 extreme points = fewer than 3 unique points or a collinear cluster: the reference drops it (:70-76)
     for (int qq = 0; qq < ng; ++qq) {
-      const int nv = __shfl(nvert, qq * 16, 64);
+      const int nv = __builtin_amdgcn_readlane(nvert, qq * 16);
       if (nv >= 3) {
         if (n_out >= n_obs_max || nv > v_max) ovf = 1;
         else {
-          const double* ring = stage_ + qq * VSTAGE * 2;
-          if (oxy) for (int v = lane; v < nv * 2; v += 64) oxy[(long)n_out * v_max * 2 + v] = ring[v];
+          const unsigned short* ringi = stagei_ + qq * VSTAGE;
+          if (oxy) for (int v = lane; v < nv * 2; v += 64) oxy[(long)n_out * v_max * 2 + v] = pint_[2 * ringi[v >> 1] + (v & 1)];
           if (onv && lane == 0) onv[n_out] = nv;
           if (oce) {
             // ---- 4. constraint assembly: closest point c and unit normal eta of this hull at the CoM, one edge per lane
@@ -632,12 +737,16 @@ __global__ __launch_bounds__(64) void lidar_sense_kernel(
 #pragma clang fp contract(off)
             const bool eon = lane < nv;
             const int ia = eon ? lane : 0, ib = (ia + 1 == nv) ? 0 : ia + 1, ip = (ia == 0) ? nv - 1 : ia - 1;
-            const EdgeCp ec = edge_closest(ring[2 * ip], ring[2 * ip + 1], ring[2 * ia], ring[2 * ia + 1], ring[2 * ib],
-                                           ring[2 * ib + 1], x0, y0);
+            const double* vp = pint_ + 2 * ringi[ip];
+            const double* va = pint_ + 2 * ringi[ia];
+            const double* vb = pint_ + 2 * ringi[ib];
+            const EdgeCp ec = edge_closest(vp[0], vp[1], va[0], va[1], vb[0], vb[1], x0, y0);
             double dmin = eon ? ec.d : INFINITY;
-            for (int m = 1; m < 64; m <<= 1) dmin = fmin(dmin, __shfl_xor(dmin, m, 64));
+            dmin = fmin(dmin, lipmpc_dev::row_xor<1>(dmin)); dmin = fmin(dmin, lipmpc_dev::row_xor<2>(dmin));
+            dmin = fmin(dmin, lipmpc_dev::row_xor<4>(dmin)); dmin = fmin(dmin, lipmpc_dev::row_xor<8>(dmin));
+            dmin = fmin(dmin, wave_xor16(dmin)); dmin = fmin(dmin, wave_xor32(dmin));
             const int sel = __ffsll((long long)__ballot(eon && ec.d == dmin)) - 1;      // >= 0: lane 0 is always an edge
-            const double ccx = __shfl(ec.qx, sel, 64), ccy = __shfl(ec.qy, sel, 64);
+            const double ccx = lane_value(ec.qx, sel), ccy = lane_value(ec.qy, sel);
             const bool inside = (__popcll(__ballot(eon && ec.hit)) & 1) != 0;
             bool degen = __any(eon && ec.degen);
             double nx = x0 - ccx, ny = y0 - ccy;
@@ -680,13 +789,39 @@ __global__ __launch_bounds__(64) void lidar_weight_kernel(long B, int R, int n_e
     if (nv <= 0) continue;
     const double* ring = exy + (long)j * v_env * 2;
     double mx = 0.0, my = 0.0, rad2 = 0.0;
-    for (int e = 0; e < nv; ++e) { mx += ring[2 * e]; my += ring[2 * e + 1]; }
-    mx /= nv; my /= nv;
-    for (int e = 0; e < nv; ++e) { const double dx = ring[2 * e] - mx, dy = ring[2 * e + 1] - my; rad2 = fmax(rad2, dx * dx + dy * dy); }
+    bool within = false;             // the robot stands INSIDE this obstacle: every ray returns a reading (the heaviest scans there are)
+    auto crosses = [&](double ax, double ay, double bx, double by) {      // edge a -> b against the +x ray from the robot
+      return ((ay > y0) != (by > y0)) && (x0 - ax) * fabs(by - ay) < (bx - ax) * (y0 - ay) * ((by > ay) ? 1.0 : -1.0);
+    };
+    if (v_env <= VFAST) {            // the whole ring in one round of loads
+      double vx[VFAST], vy[VFAST];
+#pragma unroll
+      for (int e = 0; e < VFAST; ++e) { const int ee = e < nv ? e : 0; vx[e] = ring[2 * ee]; vy[e] = ring[2 * ee + 1]; }
+#pragma unroll
+      for (int e = 0; e < VFAST; ++e) if (e < nv) { mx += vx[e]; my += vy[e]; }
+      mx /= nv; my /= nv;
+#pragma unroll
+      for (int e = 0; e < VFAST; ++e)
+        if (e < nv) {
+          const double dx = vx[e] - mx, dy = vy[e] - my;
+          rad2 = fmax(rad2, dx * dx + dy * dy);
+          const bool last = e + 1 == nv;
+          within ^= crosses(vx[e], vy[e], last ? vx[0] : vx[(e + 1) % VFAST], last ? vy[0] : vy[(e + 1) % VFAST]);
+        }
+    } else {
+      for (int e = 0; e < nv; ++e) { mx += ring[2 * e]; my += ring[2 * e + 1]; }
+      mx /= nv; my /= nv;
+      for (int e = 0; e < nv; ++e) {
+        const double dx = ring[2 * e] - mx, dy = ring[2 * e + 1] - my;
+        rad2 = fmax(rad2, dx * dx + dy * dy);
+        const int f = e + 1 == nv ? 0 : e + 1;
+        within ^= crosses(ring[2 * e], ring[2 * e + 1], ring[2 * f], ring[2 * f + 1]);
+      }
+    }
     const double rad = sqrt(rad2), d = sqrt((mx - x0) * (mx - x0) + (my - y0) * (my - y0));
     if (d > lidar_range + rad) continue;
     const double inside = (d + rad <= lidar_range) ? 1.0 : fmin(1.0, fmax(0.0, (lidar_range + rad - d) / (2.0 * rad + 1e-300)));
-    w += (d <= rad) ? (double)R : (double)R * (1.0 / M_PI) * fmin(1.0, rad / d) * inside;
+    w += within ? (double)R : (double)R * (1.0 / M_PI) * fmin(1.0, rad / fmax(d, 1e-300)) * inside;
   }
   for (int m = 1; m < 64; m <<= 1) w += __shfl_xor(w, m, 64);
   if (lane == 0) sched[SCHED_ORDER + B + b] = (int32_t)fmin(w, (double)R);
@@ -694,24 +829,56 @@ __global__ __launch_bounds__(64) void lidar_weight_kernel(long B, int R, int n_e
 
 // The launch order of the scans from the weights: robots by descending weight (counting sort, one workgroup; which of two
 // equally heavy robots comes first is immaterial).
-__global__ __launch_bounds__(1024) void lidar_order_kernel(long B, int32_t* __restrict__ sched) {
-  __shared__ int cursor_[RMAX + 1];
+__global__ __launch_bounds__(1024) void lidar_order_kernel(long B, int period, int32_t* __restrict__ sched) {
+  constexpr int NBIN = 512;                                // >= RMAX + 1 weights; one thread per bin in the scan
+  static_assert(RMAX + 1 <= NBIN, "one bin per weight");
+  __shared__ int cursor_[NBIN];
+  __shared__ int scan_[NBIN];
   const int32_t* w = sched + SCHED_ORDER + B;
   int32_t* order = sched + SCHED_ORDER;
-  for (int k = threadIdx.x; k <= RMAX; k += blockDim.x) cursor_[k] = 0;
+  for (int k = threadIdx.x; k < NBIN; k += blockDim.x) cursor_[k] = 0;
   __syncthreads();
   for (long i = threadIdx.x; i < B; i += blockDim.x) atomicAdd(&cursor_[RMAX - min(max(w[i], 0), RMAX)], 1);
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int k = 0; k <= RMAX; ++k) { const int c = cursor_[k]; cursor_[k] = run; run += c; }
+  // exclusive prefix sum of the bin counts (Hillis-Steele over the first NBIN threads; a serial loop of one thread was most of
+  // this kernel's time)
+  const int t = threadIdx.x;
+  int mine = t < NBIN ? cursor_[t] : 0, acc = mine;
+  for (int d = 1; d < NBIN; d <<= 1) {
+    if (t < NBIN) scan_[t] = acc;
+    __syncthreads();
+    if (t < NBIN && t >= d) acc += scan_[t - d];
+    __syncthreads();
   }
+  if (t < NBIN) cursor_[t] = acc - mine;
   __syncthreads();
-  for (long i = threadIdx.x; i < B; i += blockDim.x) order[atomicAdd(&cursor_[RMAX - min(max(w[i], 0), RMAX)], 1)] = (int32_t)i;
+  // Rank -> launch position.  While every wave of the grid is resident at once, launch positions `period` apart share a SIMD
+  // (period = 4 x compute units: the dispatcher deals single-wave blocks round-robin, tools/lidar_placement.py), so the ranks go
+  // out boustrophedon -- forwards on even rounds of `period` positions, backwards on odd ones: a SIMD's robots are one from each
+  // quantile, the heaviest with the lightest.  (Beyond what is resident the dispatcher takes blocks as slots free up, and plain
+  // heaviest-first is the right order there: the last, partial round stays as ranked.)
+  for (long i = threadIdx.x; i < B; i += blockDim.x) {
+    const long r = atomicAdd(&cursor_[RMAX - min(max(w[i], 0), RMAX)], 1);
+    const long q = r / period, s2 = r % period;
+    const long pos = ((q + 1) * period <= B && (q & 1)) ? q * period + (period - 1 - s2) : r;
+    order[pos] = (int32_t)i;
+  }
   if (threadIdx.x == 0) sched[SCHED_VALID] = (int32_t)B;
 }
 
 }  // namespace
+
+// SIMDs of the device (4 per compute unit), asked once per device
+static int simd_count(int device) {
+  static int cached[64];
+  if (device < 0 || device >= 64) return 1024;
+  if (cached[device] == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    cached[device] = 4 * cus;
+  }
+  return cached[device];
+}
 
 static int lidar_launch(int device, int64_t B, int32_t resolution, int32_t n_env, int32_t v_env, int32_t env_shared,
                         double lidar_range, double eps, int32_t min_samples, int32_t n_obs_max, int32_t v_max,
@@ -719,6 +886,7 @@ static int lidar_launch(int device, int64_t B, int32_t resolution, int32_t n_env
                         const double* noise, double* obs_xy, int32_t* obs_nv, double* c_eta, int32_t* n_inferred,
                         int32_t* overflow, double* hits, int32_t* labels, int32_t* schedule, void* hip_stream) {
   if (B < 0 || resolution < 1 || resolution > RMAX || n_env < 0 || v_env < 1 || n_obs_max < 1 || v_max < 3 || v_max > VSTAGE) return LIPMPC_E_ARG;
+  if (n_env > 65535) return LIPMPC_E_UNSUPPORTED;      // obstacle indices are kept as 16 bits in LDS
   if (B == 0) return LIPMPC_OK;
   if (!state || !ray_table || !n_inferred || !overflow || (n_env > 0 && (!env_xy || !env_nv)) || (!obs_xy != !obs_nv) ||
       (!obs_xy && !c_eta))
@@ -735,7 +903,7 @@ static int lidar_launch(int device, int64_t B, int32_t resolution, int32_t n_env
     // rank the robots first: estimate of the reading counts -> order, heaviest first; the scans then start in that order
     hipLaunchKernelGGL(lidar_weight_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)hip_stream, (long)B, resolution, n_env, v_env,
                        (long)(env_shared ? 0 : 1), lidar_range, state, env_xy, env_nv, schedule);
-    hipLaunchKernelGGL(lidar_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, (long)B, schedule);
+    hipLaunchKernelGGL(lidar_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, (long)B, simd_count(device), schedule);
   } else {
     schedule = nullptr;
   }

@@ -246,7 +246,7 @@ int lipmpc_rollout_batch(lipmpc_handle* h, int64_t B, int32_t k_max, int32_t mpc
  * come out in the layout lipmpc_plan_step_batch takes as obs_xy / obs_nv.
  *  state      [B,5]  only (p_x, p_y) are read
  *  env_xy     [n_env,v_env,2] if env_shared else [B,n_env,v_env,2]; env_nv likewise: the TRUE map as vertex rings
- *             in the order the reference iterates them (`ch.points`, HumanoidMPCUnknownEnvironment.py:46)
+ *             in the order the reference iterates them (`ch.points`, HumanoidMPCUnknownEnvironment.py:46); n_env <= 65535
  *  ray_table  [resolution,2] (cos, sin) of angle_i = i * 2 pi / resolution, computed on the host (bit-identical
  *             directions to the reference's math.cos / math.sin); resolution <= 384
  *  noise      [B,resolution,2] added to valid readings, or NULL.  The reference draws N(0, 0.01) from numpy's

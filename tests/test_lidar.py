@@ -545,7 +545,13 @@ def test_gpu_constraint_assembly_fused_into_the_scan(golden_dir):
         assert torch.equal(got_s["n_inferred"], lean["n_inferred"]) and torch.equal(got_s["overflow"], lean["overflow"])
         sc = sched.cpu().numpy()
         assert sc[0] == B and np.array_equal(np.sort(sc[2:2 + B]), np.arange(B))               # a complete order of the B robots ...
-        assert np.all(np.diff(sc[2 + B:][sc[2:2 + B]]) <= 0)                                   # ... by descending estimated reading count
+        # ... by descending estimated reading count, dealt out boustrophedon over rounds of one position per SIMD (positions one
+        # round apart share a SIMD while the whole grid is resident: each gets a heavy robot with a light one)
+        period = 4 * torch.cuda.get_device_properties(0).multi_processor_count
+        ranked = sc[2:2 + B].copy()
+        for q in range(1, B // period, 2):
+            ranked[q * period:(q + 1) * period] = ranked[q * period:(q + 1) * period][::-1]
+        assert np.all(np.diff(sc[2 + B:][ranked]) <= 0)
     with pytest.raises(ValueError):
         sensor.sense(d_st[:100].contiguous(), noise[:100].contiguous(), c_eta=True, schedule=sched)
     # the whole step of the unknown-environment variant in one C call

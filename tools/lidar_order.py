@@ -44,3 +44,37 @@ binid = (npts[:, None] < bins[None, :]).sum(1)                      # 0 = heavie
 idx = torch.argsort(binid, stable=True)
 s4, n4 = state[idx].contiguous(), noise[idx].contiguous()
 print("sorted by BIN only (plain launch)   %.1f us" % t(lambda: sensor.sense(s4, n4, out=sen, schedule=None)))
+# Every robot is resident at once at 16 waves per CU (4096 robots = 4096 wave slots): what matters then is which robots SHARE a
+# SIMD.  Snake orders by the true counts: ranks q P .. q P + P - 1 go to positions q P + s forwards on even rounds q, backwards on
+# odd ones, so that positions P apart (the same SIMD, if the dispatcher deals blocks round-robin with that period) hold a heavy
+# and a light robot.
+rank = torch.argsort(npts, descending=True)
+for P in (64, 256, 512, 1024, 2048):
+    if B % P:
+        continue
+    pos_rank = torch.arange(B, device=dev).view(B // P, P).clone()
+    pos_rank[1::2] = pos_rank[1::2].flip(1)
+    idx = rank[pos_rank.flatten()]
+    s5, n5 = state[idx].contiguous(), noise[idx].contiguous()
+    print("snake, period %4d (plain launch)   %.1f us" % (P, t(lambda: sensor.sense(s5, n5, out=sen, schedule=None))))
+# Positions p, p + P, p + 2P, p + 3P share a SIMD (P = 4 x CUs = 1024: tools/lidar_placement.py).  Folded pairs, and greedy
+# longest-processing-time-first per round (each round's ranks go to the SIMDs by ascending load) on two cost models.
+P = 1024
+if B == 4 * P:
+    s = torch.arange(P, device=dev)
+    idx = rank[torch.cat([s, 2 * P - 1 - s, 3 * P - 1 - s, 3 * P + s])]
+    s6, n6 = state[idx].contiguous(), noise[idx].contiguous()
+    print("fold pairs (s, 2P-1-s, 3P-1-s, 3P+s)      %.1f us" % t(lambda: sensor.sense(s6, n6, out=sen, schedule=None)))
+    for label, cost in (("n", npts.double()), ("11 + 0.09 n", 11 + 0.09 * npts.double()), ("11 + 0.09 n, blobs 43", torch.where(npts >= 330, 43.0, 11 + 0.06 * npts.double()))):
+        cs = cost[rank]
+        load = torch.zeros(P, dtype=torch.float64, device=dev)
+        pos = []
+        for q in range(4):
+            simd = torch.argsort(load)                     # least loaded first gets the heaviest of the round
+            pos_q = torch.empty(P, dtype=torch.long, device=dev)
+            pos_q[simd] = torch.arange(q * P, (q + 1) * P, device=dev)
+            load = load + cs[pos_q]
+            pos.append(pos_q)
+        idx = rank[torch.cat(pos)]
+        s7, n7 = state[idx].contiguous(), noise[idx].contiguous()
+        print("LPT per round on cost %-24s %.1f us  (model load max / mean %.2f)" % (label, t(lambda: sensor.sense(s7, n7, out=sen, schedule=None)), (load.max() / load.mean()).item()))

@@ -3,4 +3,4 @@
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 test -f $R/variants/phases.so
-for s in 1 2 3 0; do LIPMPC_LIB=$R/variants/phases.so LIPMPC_LIDAR_STOP=$s python3 $R/tools/lidar_uniform.py 2>&1 | grep -v amdgpu.ids; done
+for s in ${LIDAR_STOPS:-1 2 3 0}; do LIPMPC_LIB=$R/variants/phases.so LIPMPC_LIDAR_STOP=$s python3 $R/tools/lidar_uniform.py 2>&1 | grep -v amdgpu.ids; done
