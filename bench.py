@@ -612,7 +612,7 @@ def other_configs(lipmpc, synth, dev, full=False):
     o = solver.alloc_outputs(B)
     sen = sensor.alloc_outputs(B, rings=False, c_eta=True)
     # robots handed over as they come; the call ranks them itself (estimate of the reading counts from the obstacles' bounding
-    # circles -> counting sort -> scans started heaviest first: two small kernels inside the timed call, nothing carried over
+    # circles -> counting sort -> launch positions, a heavy robot with light ones per SIMD: two small kernels inside the timed call, nothing carried over
     # between calls).  ms_scan_unranked: the same call without the order buffer (scans start in index order).
     sched = sensor.make_schedule(B)
     ms_scan = _time_ms(lambda: sensor.sense(state, noise, out=sen, schedule=sched))
@@ -622,7 +622,7 @@ def other_configs(lipmpc, synth, dev, full=False):
     out["config5_lidar"] = {"batch": B, "ms_scan": ms_scan, "ms_step": ms_step,
                             "robot_steps_per_s": B / (ms_scan + ms_step) * 1e3,
                             "ms_scan_unranked": ms_scan_unranked, "robot_steps_per_s_unranked": B / (ms_scan_unranked + ms_step) * 1e3,
-                            "launch_order": "robots handed over in index order; the call ranks them by estimated reading count and scans the heaviest first (ranking included in ms_scan)",
+                            "launch_order": "robots handed over in index order; the call ranks them by estimated reading count and deals them out a heavy one with light ones per SIMD (ranking included in ms_scan)",
                             "mean_inferred_obstacles": float(sen["n_inferred"].double().mean()),
                             "overflow": int(sen["overflow"].sum())}
     # config 5 on PER-ROBOT maps of the reference's unknown-environment scenario shape (Scenario.load_scenario(CROWDED, start (0,0),

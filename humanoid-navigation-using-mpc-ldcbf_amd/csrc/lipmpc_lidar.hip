@@ -5,19 +5,23 @@
 //       HumanoidNavigation/RangeFinder/range_finder_wth_polygons_dbscan.py:26-63, 65-83, 100-126, 157-180
 //   line_polygon_intersection (compute_intersection)      HumanoidNavigation/Utils/obstacles.py:95-139
 //   the call site                                          HumanoidNavigation/MPC/HumanoidMPCVariants/HumanoidMPCUnknownEnvironment.py:30-68
-// One wavefront (64 lanes) per robot; everything between the ray casting and the half-spaces stays in LDS / registers:
+// One wavefront (64 lanes) per robot; everything between the ray casting and the half-spaces stays in LDS / registers
+// (10.1 KB of LDS and 128 registers per wave: 16 waves per CU, a whole batch of 4096 robots resident at once):
 //   1. rays: lane l owns rays l, l+64, ...; the edges of the obstacles within range are staged once per robot in LDS
-//      (edge vector and the robot's offset from the edge's first vertex: the operands of compute_intersection, no
-//      global / scalar load left in the ray loops) and every ray walks them in list order, keeping the nearest hit
-//      strictly inside the range (contraction off: the hit points are bit-identical to the reference's)
+//      (edge vector, the robot's offset from the edge's first vertex and their cross product: the operands of
+//      compute_intersection, no global / scalar load left in the ray loops) and every ray walks them in list order, keeping
+//      the nearest hit strictly inside the range (contraction off: the hit points are bit-identical to the reference's)
 //   2. DBSCAN(eps, min_samples) by its order-free characterisation (oracle/lidar_oracle.py), on the readings
-//      compacted in ray order: neighbour bit rows, core flags, connected components of the core points (forest of
-//      "smallest core neighbour" pointers + pointer jumping, then merging trees through ballot masks of tree
-//      membership — bit operations, no sweeps over neighbours' labels), clusters numbered by their smallest core
-//      index, border points to the smallest neighbouring cluster
+//      compacted in ray order: neighbour bit rows (pruned by the bounding boxes of runs of 16 readings: far pairs of runs
+//      skipped, pairs within eps corner to corner set without a test, the rest tested column by column with the verdict
+//      shifted in through the carry), core flags, connected components of the core points (forest of "smallest core
+//      neighbour" pointers + pointer jumping, then merging trees through ballot masks of tree membership — bit operations,
+//      no sweeps over neighbours' labels), clusters numbered by their smallest core index, border points to the smallest
+//      neighbouring cluster
 //   3. hull per cluster: Jarvis march from the lexicographically smallest point, farthest point on collinear ties
 //      (= the CCW ring of extreme points Qhull / monotone chain return, same rotation as np.unique + monotone chain);
-//      four clusters march at once, one per 16-lane DPP row, over compacted member lists
+//      four clusters march at once, one per 16-lane DPP row, every lane's candidates held in registers; a step's winner is
+//      guessed by a single-precision turning key and proved with the exact predicate (exact reduction only when that fails)
 //   4. constraint assembly (HumanoidMPCUnknownEnvironment.py:54-62 -> ObstaclesUtils.py:60-109): closest point c and
 //      unit normal eta of every hull at the robot's CoM, one hull edge per lane, from the hull still staged in LDS --
 //      the (c, eta) rows are what the step solver consumes (lipmpc_plan_step_batch_c_eta); the rings themselves go to
@@ -36,7 +40,7 @@ namespace {
 constexpr int RMAX = 384;            // rays per scan (reference: 360)
 constexpr int WORDS = RMAX / 64;     // neighbour bit row
 constexpr int NO_ROOT = 0x7fffffff;
-constexpr int SOLO_MIN = 48;        // a cluster of at least this many points gets the whole wave in the hull stage
+constexpr int SOLO_MIN = 64;        // a cluster of at least this many points gets the whole wave in the hull stage
 constexpr int NCC = 64;             // candidates whose bounding circle is kept for the per-pass sector test
 constexpr int VFAST = 8;            // rings of at most this many vertices (v_env) are fetched in one round of loads
 constexpr int VSTAGE = 64;          // hull vertices staged per cluster (v_max <= VSTAGE)
@@ -52,9 +56,6 @@ struct Cand { double x, y; int idx; };
 #define LIDAR_PHASE_END(n) if (dbg_stop == (n)) return
 #else
 #define LIDAR_PHASE_END(n)
-#endif
-#ifndef LIDAR_WAVES
-#define LIDAR_WAVES 4
 #endif
 
 // Is candidate b a better "next hull vertex" than a when standing on p?  (b strictly to the right of p->a, or collinear and
@@ -120,7 +121,7 @@ __device__ __forceinline__ EdgeCp edge_closest(double pvx, double pvy, double ax
   return r;
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LIDAR_WAVES, LIDAR_WAVES))) void lidar_sense_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void lidar_sense_kernel(
     long B, int R, int n_env, int v_env, long env_stride, double lidar_range, double eps, int min_samples,
     int n_obs_max, int v_max, const double* __restrict__ state, const double* __restrict__ env_xy,
     const int32_t* __restrict__ env_nv, const double* __restrict__ ray_table, const double* __restrict__ noise,
@@ -147,10 +148,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LIDAR_WAVES,
   const int lane = threadIdx.x;
   if ((long)blockIdx.x >= B) return;
   // Which robot this wave scans: the block index, or -- with an order buffer (include/lipmpc.h) -- the robot the order
-  // kernel of THIS call put at this position: heaviest first, by an estimate of its reading count (lidar_weight_kernel).  A
-  // scan's length varies 3x with the number of readings (all-pairs clustering), 4096 robots run in two rounds on the 2048 wave
-  // slots, and a heavy robot started late sets the launch time: 241 us as the robots come, 159 us heaviest first by the true
-  // counts (tools/lidar_order.py).  Any order gives the same results.
+  // kernel of THIS call put at this position: ranked by an estimate of its reading count (lidar_weight_kernel) and dealt out so
+  // that the robots sharing a SIMD are a heavy one with light ones (lidar_order_kernel).  A scan's length varies 3x with the
+  // number of readings, and with the whole batch resident the launch lasts as long as its most loaded SIMD: 155 us as the robots
+  // come, 112 us ranked by the true counts, 123 us ranked by the estimate, ranking included (tools/lidar_order.py).  Any order
+  // gives the same results.
   long b = blockIdx.x;
   if (sched && sched[SCHED_VALID] == (int)B) {
     const long r = sched[SCHED_ORDER + blockIdx.x];
@@ -632,6 +634,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LIDAR_WAVES,
     const int k = g + qrow;
     const bool on = qrow < ng;
     const int beg = on ? coff_[k] : 0, end = on ? coff_[k + 1] : 0;
+    // candidate slots in use (wave-uniform: the group's largest cluster decides): the unused ones cost nothing
+    int njw = (end - beg + W - 1) / W;
+    njw = max(njw, wave_xor16(njw)); njw = max(njw, wave_xor32(njw));
+    const int nj = __builtin_amdgcn_readfirstlane(njw);
     Cand c[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -643,7 +649,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LIDAR_WAVES,
     // lexicographically smallest point of the cluster
     Cand st; st.idx = -1; st.x = 0.0; st.y = 0.0;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) if (lex(st, c[j])) st = c[j];
+    for (int j = 0; j < NJ; ++j) if (j < nj && lex(st, c[j])) st = c[j];
     if (SOLO) wave_best(st, lex); else row_best(st, lex);
     // Jarvis march (of the rows in lock step)
     double cxp = st.x, cyp = st.y;
@@ -669,6 +675,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LIDAR_WAVES,
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
 #pragma clang fp contract(off)
+        if (j >= nj) continue;
         r[j].x = c[j].x - cxp; r[j].y = c[j].y - cyp;
         r[j].idx = ((r[j].x == 0.0) & (r[j].y == 0.0)) ? -1 : c[j].idx;
         const float fx = (float)r[j].x, fy = (float)r[j].y;
@@ -691,13 +698,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LIDAR_WAVES,
         best.x = pint_[2 * gi] - cxp; best.y = pint_[2 * gi + 1] - cyp; best.idx = kidx;
         if (kidx < 0) { best.x = 0.0; best.y = 0.0; }
       }
-      bool beaten = false;
+      // (the proof, straight-line: a candidate strictly to the right of p -> guess beats it; one exactly in line with it --
+      // other than the guess itself -- sends the wave to the full predicate)
+      bool beaten = false, in_line = false;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) beaten |= better_from(best, r[j]);
+      for (int j = 0; j < NJ; ++j) {
+#pragma clang fp contract(off)
+        if (j >= nj) continue;
+        const double cr = best.x * r[j].y - best.y * r[j].x;
+        const bool valid = r[j].idx >= 0;
+        beaten |= valid & ((best.idx < 0) | (cr < 0.0));
+        in_line |= valid & (cr == 0.0) & (r[j].idx != best.idx);
+      }
+      if (__any(in_line)) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) if (j < nj) beaten |= better_from(best, r[j]);
+      }
       if (__any(beaten)) {                                               // the exact reduction
         best.idx = -1; best.x = 0.0; best.y = 0.0;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) if (better_from(best, r[j])) best = r[j];
+        for (int j = 0; j < NJ; ++j) if (j < nj && better_from(best, r[j])) best = r[j];
         auto right = [&](const Cand& a, const Cand& o) { return better_from(a, o); };
         if (SOLO) wave_best(best, right); else row_best(best, right);
       }
@@ -769,11 +789,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LIDAR_WAVES,
   if (lane == 0) { n_inferred[b] = n_out; overflow[b] = ovf; }
 }
 
-// Weight of every robot for the launch order of its scan: an ESTIMATE of its reading count from the bounding circles of the
-// obstacles in range -- the rays a circle of radius r at distance d subtends, R / (2 pi) * 2 asin(r / d) (the asin by its
-// argument: the estimate only ranks), scaled by the share of the circle inside the range, summed and capped at R.  Correlation
-// 0.76 with the true counts on a CROWDED-style map, 27 of the 30 heaviest robots in its top 60: enough for
-// "heaviest first", and it costs one obstacle per lane instead of the scan itself.  One wave per robot.
+// Weight of every robot for the launch order of its scan: an ESTIMATE of its reading count -- every ray, if the robot stands
+// INSIDE an obstacle (the heaviest scans there are: all 360 readings in one dense cluster); otherwise, per obstacle in range, the
+// rays its bounding circle of radius r at distance d subtends, R / (2 pi) * 2 asin(r / d) (the asin by its argument: the estimate
+// only ranks), scaled by the share of the circle inside the range -- summed and capped at R.  Correlation 0.91 with the true
+// counts on a CROWDED-style map, 93 % of the heaviest tenth in its top fifth (tools/lidar_order.py): it costs one obstacle per
+// lane instead of the scan itself.  One wave per robot.
 __global__ __launch_bounds__(64) void lidar_weight_kernel(long B, int R, int n_env, int v_env, long env_stride, double lidar_range,
                                                           const double* __restrict__ state, const double* __restrict__ env_xy,
                                                           const int32_t* __restrict__ env_nv, int32_t* __restrict__ sched) {
@@ -893,14 +914,14 @@ static int lidar_launch(int device, int64_t B, int32_t resolution, int32_t n_env
     return LIPMPC_E_ARG;
   if (hipSetDevice(device) != hipSuccess) return LIPMPC_E_HIP;
 #ifdef LIPMPC_LIDAR_PHASES
-  // profiling build only (make CXXFLAGS+=-DLIPMPC_LIDAR_PHASES, tools/lidar_phases.py): LIPMPC_LIDAR_STOP=1..5 ends the
+  // profiling build only (make CXXFLAGS+=-DLIPMPC_LIDAR_PHASES, tools/lidar_phases.py): LIPMPC_LIDAR_STOP=1..7 ends the
   // kernel after that phase; outputs are then undefined.  The shipped library has no such knob.
   static const int dbg_stop = getenv("LIPMPC_LIDAR_STOP") ? atoi(getenv("LIPMPC_LIDAR_STOP")) : 0;
 #else
   const int dbg_stop = 0;
 #endif
   if (schedule && n_env > 0) {
-    // rank the robots first: estimate of the reading counts -> order, heaviest first; the scans then start in that order
+    // rank the robots first: estimate of the reading counts -> launch positions, a heavy robot with light ones on every SIMD
     hipLaunchKernelGGL(lidar_weight_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)hip_stream, (long)B, resolution, n_env, v_env,
                        (long)(env_shared ? 0 : 1), lidar_range, state, env_xy, env_nv, schedule);
     hipLaunchKernelGGL(lidar_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, (long)B, simd_count(device), schedule);

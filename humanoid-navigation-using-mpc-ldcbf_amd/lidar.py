@@ -62,7 +62,7 @@ class LidarSensor:
 
     def make_schedule(self, B):
         """An order buffer for ``sense(..., schedule=)`` (lipmpc_lidar_c_eta_batch): scratch in which the call ranks its B
-        robots by an estimate of their reading counts and from which it starts their scans heaviest first.  Nothing carries
+        robots by an estimate of their reading counts and deals their scans out so that every SIMD gets a heavy one with light ones.  Nothing carries
         over between calls; results do not depend on it."""
         return torch.zeros((int(self.lib.lipmpc_lidar_schedule_words(B)),), dtype=torch.int32, device=self.device)
 
@@ -74,7 +74,7 @@ class LidarSensor:
         ``BatchedLipMpc.plan_step_batch_c_eta`` solves against; with ``rings=False`` the hulls never leave the kernel.
         ``schedule``: a buffer of ``make_schedule(B)``, None (robots scanned in index order), or "auto" (default): with
         ``c_eta=True`` and more than one round of waves the sensor keeps one order buffer per (batch size, current stream) and
-        every scan first ranks its robots (estimated reading counts, heaviest first: two small kernels inside the call).  Any
+        every scan first ranks its robots (estimated reading counts -> launch positions: two small kernels inside the call).  Any
         order gives the same results -- but scans that share a BUFFER must be ordered on one stream (the order kernel of one
         launch rewrites what another launch reads; a torn order would scan some robots twice and others not at all): a buffer
         of ``make_schedule`` handed to launches on two streams, or to two graphs replayed concurrently, is a caller's bug.
@@ -273,7 +273,7 @@ class UnknownEnvFleet:
                   sen=sn.alloc_outputs(B, rings=False, c_eta=True),      # hulls stay in the scan kernel: only (c, eta) rows reach HBM
                   out=sv.alloc_outputs(B), nbuf=None if noise_mode == "none" else torch.zeros((B, sn.resolution, 2), **f64),
                   gen=torch.Generator(device=dev) if noise_mode == "seeded" else None, graph=None,
-                  sched=sn.make_schedule(B))                 # order buffer: every scan ranks its robots and starts the heaviest first
+                  sched=sn.make_schedule(B))                 # order buffer: every scan ranks its robots before it starts them
         self._plan = pl
         return pl
 

@@ -277,11 +277,12 @@ int lipmpc_lidar_sense_batch(int device, int64_t B, int32_t resolution, int32_t 
  *  n_inferred [B], overflow [B] as lipmpc_lidar_sense_batch
  *  obs_xy / obs_nv: the rings as well, or both NULL;  hits, labels: or NULL
  *  schedule: NULL (the robots are scanned in index order), or a device buffer of lipmpc_lidar_schedule_words(B) int32, contents
- *        arbitrary: scratch for the LAUNCH ORDER of this call.  A scan's length grows with its reading count (all-pairs
- *        clustering) and 4096 robots run in two rounds of waves, so a heavy robot started late sets the launch time.  With
- *        the buffer the call first ranks its robots -- one small kernel estimates every robot's reading count from the bounding
- *        circles of the obstacles in range, a one-workgroup counting sort turns the estimates into an order, heaviest first --
- *        and then starts the scans in that order (both included in the call: ~10 us per 4096 robots).  Nothing carries over
+ *        arbitrary: scratch for the LAUNCH ORDER of this call.  A scan's length grows with its reading count, a whole batch of
+ *        4096 robots is resident at once (16 waves per compute unit), and the launch lasts as long as its most loaded SIMD.  With
+ *        the buffer the call first ranks its robots -- one small kernel estimates every robot's reading count (all rays for a
+ *        robot inside an obstacle, else from the bounding circles of the obstacles in range), a one-workgroup counting sort
+ *        turns the estimates into launch positions that give every SIMD a heavy robot with light ones -- and then starts
+ *        the scans in that order (both included in the call: ~11 us per 4096 robots).  Nothing carries over
  *        from one call to the next; every order gives the same results; calls sharing a buffer must be stream-ordered. */
 int lipmpc_lidar_c_eta_batch(int device, int64_t B, int32_t resolution, int32_t n_env, int32_t v_env,
                              int32_t env_shared, double lidar_range, double eps, int32_t min_samples,

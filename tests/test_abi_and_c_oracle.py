@@ -92,6 +92,8 @@ def test_default_params_are_the_reference_config():
     z = C.c_void_p(0)
     assert lib.lipmpc_lidar_c_eta_batch(0, 1, 360, 0, 1, 1, C.c_double(1.5), C.c_double(0.3), 3, 12, 32, *([z] * 14)) == -1   # no c_eta
     assert lib.lipmpc_sense_plan_step_batch(z, 1, 360, 0, 1, 1, C.c_double(1.5), C.c_double(0.3), 3, *([z] * 24)) == -1       # no handle
+    one = C.c_void_p(8)                                                                                                        # (never dereferenced)
+    assert lib.lipmpc_lidar_c_eta_batch(0, 1, 360, 70000, 5, 1, C.c_double(1.5), C.c_double(0.3), 3, 12, 32, *([one] * 14)) == -2  # obstacle indices are 16 bits in LDS
 
 
 def test_create_without_gpu_fails_cleanly():
@@ -285,6 +287,27 @@ def test_headline_kernel_resource_report():
         val = lambda key: int(re.search(key + r"[^:]*: (\d+)", blk[0]).group(1))
         assert val("ScratchSize") == 0 and val("Occupancy") == 1, (nl, val("ScratchSize"))
         assert val("SGPRs Spill") <= 160, (nl, val("SGPRs Spill"))
+
+
+def test_lidar_kernel_resource_report():
+    """The scan's occupancy is what its resource report says it is: 128 registers and at most 10 KB of LDS per wave = 16
+    waves per compute unit (a whole batch of 4096 robots resident at once, which the launch order of lidar_order_kernel is
+    built on), no scratch, no register spilled to memory."""
+    import re
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "humanoid-navigation-using-mpc-ldcbf_amd", "csrc", "lipmpc_lidar.hip")
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", os.devnull,
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blk = [b for b in re.split(r"remark: Function Name: ", r.stderr)[1:] if "lidar_sense_kernel" in b.split()[0]]
+    assert len(blk) == 1
+    val = lambda key: int(re.search(key + r"[^:]*: (\d+)", blk[0]).group(1))
+    assert val("ScratchSize") == 0 and val("VGPRs Spill") == 0
+    assert val(" VGPRs") <= 128 and val("AGPRs") == 0 and val("Occupancy") == 4
+    assert val("LDS Size") <= 10240, val("LDS Size")              # 160 KB / 16 waves
 
 
 def test_dev_variants_compile():

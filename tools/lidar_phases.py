@@ -1,4 +1,4 @@
-"""Dev tool: LiDAR kernel time up to a phase (library built with -DLIPMPC_LIDAR_PHASES, LIPMPC_LIDAR_STOP=1..5 in the
+"""Dev tool: LiDAR kernel time up to a phase (library built with -DLIPMPC_LIDAR_PHASES, LIPMPC_LIDAR_STOP=1..7 in the
 environment; 1 rays, 2 neighbour rows, 4 components, 5 cluster roots, 3 labels; 0 = whole kernel) for B robots (argv[1])."""
 import sys, os, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
