@@ -45,7 +45,7 @@ constexpr int NCC = 64;             // candidates whose bounding circle is kept 
 constexpr int VFAST = 8;            // rings of at most this many vertices (v_env) are fetched in one round of loads
 constexpr int VSTAGE = 64;          // hull vertices staged per cluster (v_max <= VSTAGE)
 // order buffer (int32, scratch of ONE call): [B the order is valid for, -, order[B] (robot at launch position i), weight[B]]
-constexpr int SCHED_VALID = 0, SCHED_ORDER = 2;
+constexpr int SCHED_VALID = 0, SCHED_PERIOD = 1, SCHED_ORDER = 2;
 constexpr int NRUN = RMAX / 16;      // runs of 16 consecutive readings
 constexpr int ECAP = 152;           // edges staged per chunk of the ray phase (5 doubles each, where the points go afterwards)
 static_assert(ECAP * 5 <= 2 * RMAX && ECAP % 2 == 0, "the staged edges live in the point array");
@@ -157,8 +157,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   if (sched && sched[SCHED_VALID] == (int)B) {
     const long r = sched[SCHED_ORDER + blockIdx.x];
     if (r >= 0 && r < B) b = r;
+    // the robots of a SIMD come one from each round of `period` launch positions, the heaviest from the first: that one goes
+    // first when the SIMD picks an instruction (the launch lasts as long as its longest scan)
+    const int period = sched[SCHED_PERIOD];
+    if (period > 0) {
+      const long round = blockIdx.x / period;
+      if (round == 0) __builtin_amdgcn_s_setprio(3);
+      else if (round == 1) __builtin_amdgcn_s_setprio(1);
+    }
   }
 #ifdef LIPMPC_LIDAR_PHASES
+  const unsigned long long t_enter = wall_clock64();
   if (dbg_stop == 8) {            // placement probe (tools/lidar_placement.py): where the dispatcher put launch position blockIdx.x
     if (lane == 0) {
       n_inferred[blockIdx.x] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
@@ -345,6 +354,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
   LIDAR_PHASE_END(1);
   // ---- 2. DBSCAN ------------------------------------------------------------------------------------
+  // The launch lasts as long as its longest scan, and a scan with many readings (quadratically more pair tests, the longest hull)
+  // shares its SIMD with three others: from here on it goes first when the SIMD picks an instruction.
+  if (n_pts > 256) __builtin_amdgcn_s_setprio(3);
+  else if (n_pts > 160) __builtin_amdgcn_s_setprio(2);
+  else if (n_pts > 112) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
   const int NW = (n_pts + 63) >> 6;                      // words / passes actually in use (wave-uniform)
   const int npad = NW << 6;
   if (labels_out) for (int i = lane; i < R; i += 64) labels_out[b * R + i] = -2;      // -2 = no reading
@@ -355,6 +370,159 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const int left = n_pts - w * 64;
     vmask[w] = left >= 64 ? ~0ull : (left <= 0 ? 0ull : ((1ull << left) - 1ull));
   }
+  int touch[WORDS];                                  // smallest tree root point lane + 64 k touches (NO_ROOT: none)
+#pragma unroll
+  for (int w = 0; w < WORDS; ++w) touch[w] = NO_ROOT;
+  // ---- 2a. the readings as chains ---------------------------------------------------------------------
+  // Readings come in ray order: consecutive ones on one obstacle's outline lie centimetres apart, eps is 0.3 m.  Cut the list
+  // where two consecutive readings are farther apart than eps: if the pieces' bounding boxes are farther than eps from one
+  // another (the first and the last piece may instead be joined across ray 0 by the pair (last, first) itself), no reading has
+  // a neighbour outside its piece; if moreover every reading of a piece of at least min_samples readings provably has
+  // min_samples - 1 neighbours among the readings one and two places from it, every reading of such a piece is a core point
+  // and the piece, being chained, is ONE cluster -- while a shorter piece holds no core point and is noise.  That is DBSCAN's
+  // answer (clusters numbered by their first reading, no border points) from three distance tests per reading instead of the
+  // neighbour rows; whenever any part of the proof fails the scan takes the general route below.
+  bool chains = false;
+  if (n_pts >= 1) {
+#pragma clang fp contract(off)
+    constexpr int SEGMAX = 8;
+    unsigned long long brk[WORDS];                   // bit l of brk[w]: reading w * 64 + l is the last of its piece
+    bool far2[WORDS], back2[WORDS];                  // this lane's reading of word w has its second neighbour after / before it within eps
+#pragma unroll
+    for (int w = 0; w < WORDS; ++w) {
+      brk[w] = 0ull; far2[w] = false; back2[w] = false;
+      if (w >= NW) continue;
+      const int i = w * 64 + lane;
+      const bool valid = i < n_pts;
+      const int i1 = min(i + 1, n_pts - 1), i2 = min(i + 2, n_pts - 1), ib = max(min(i, n_pts - 1) - 2, 0);
+      const double mx = pint_[2 * (valid ? i : 0)], my = pint_[2 * (valid ? i : 0) + 1];
+      const double d1x = mx - pint_[2 * i1], d1y = my - pint_[2 * i1 + 1];
+      const double d2x = mx - pint_[2 * i2], d2y = my - pint_[2 * i2 + 1];
+      const double dbx = mx - pint_[2 * ib], dby = my - pint_[2 * ib + 1];
+      const bool link1 = (i + 1 < n_pts) & (d1x * d1x + d1y * d1y <= eps2);
+      brk[w] = __ballot(valid & !link1);
+      far2[w] = valid & (i + 2 < n_pts) & (d2x * d2x + d2y * d2y <= eps2);
+      back2[w] = valid & (i >= 2) & (dbx * dbx + dby * dby <= eps2);
+    }
+    int nseg = 0;
+#pragma unroll
+    for (int w = 0; w < WORDS; ++w) nseg += __popcll(brk[w]);
+    // (last, first): the pair that may join the last piece to the first across ray 0
+    const double wdx = pint_[2 * (n_pts - 1)] - pint_[0], wdy = pint_[2 * (n_pts - 1) + 1] - pint_[1];
+    const bool wrap_close = n_pts >= 4 && wdx * wdx + wdy * wdy <= eps2;
+    bool ok = nseg <= SEGMAX;
+    if (ok) {
+      // bounding box, first reading and length of every piece, piece s in lane s
+      double bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY;
+      int pstart = 0, plen = 0;
+      int a = 0, s = 0;
+#pragma unroll
+      for (int w = 0; w < WORDS; ++w) {
+        unsigned long long m = brk[w];               // wave-uniform
+        while (m) {
+          const int last = w * 64 + __ffsll((long long)m) - 1;
+          m &= m - 1;
+          double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+#pragma unroll
+          for (int w2 = 0; w2 < WORDS; ++w2) {
+            if (w2 >= NW || w2 * 64 > last || w2 * 64 + 63 < a) continue;
+            const int i2 = w2 * 64 + lane;
+            const bool in = (i2 >= a) & (i2 <= last);
+            const double x = pint_[2 * (in ? i2 : a)], y = pint_[2 * (in ? i2 : a) + 1];
+            x0 = fmin(x0, x); x1 = fmax(x1, x); y0 = fmin(y0, y); y1 = fmax(y1, y);
+          }
+          x0 = fmin(x0, lipmpc_dev::row_xor<1>(x0)); x1 = fmax(x1, lipmpc_dev::row_xor<1>(x1)); y0 = fmin(y0, lipmpc_dev::row_xor<1>(y0)); y1 = fmax(y1, lipmpc_dev::row_xor<1>(y1));
+          x0 = fmin(x0, lipmpc_dev::row_xor<2>(x0)); x1 = fmax(x1, lipmpc_dev::row_xor<2>(x1)); y0 = fmin(y0, lipmpc_dev::row_xor<2>(y0)); y1 = fmax(y1, lipmpc_dev::row_xor<2>(y1));
+          x0 = fmin(x0, lipmpc_dev::row_xor<4>(x0)); x1 = fmax(x1, lipmpc_dev::row_xor<4>(x1)); y0 = fmin(y0, lipmpc_dev::row_xor<4>(y0)); y1 = fmax(y1, lipmpc_dev::row_xor<4>(y1));
+          x0 = fmin(x0, lipmpc_dev::row_xor<8>(x0)); x1 = fmax(x1, lipmpc_dev::row_xor<8>(x1)); y0 = fmin(y0, lipmpc_dev::row_xor<8>(y0)); y1 = fmax(y1, lipmpc_dev::row_xor<8>(y1));
+          x0 = fmin(x0, wave_xor16(x0)); x1 = fmax(x1, wave_xor16(x1)); y0 = fmin(y0, wave_xor16(y0)); y1 = fmax(y1, wave_xor16(y1));
+          x0 = fmin(x0, wave_xor32(x0)); x1 = fmax(x1, wave_xor32(x1)); y0 = fmin(y0, wave_xor32(y0)); y1 = fmax(y1, wave_xor32(y1));
+          if (lane == s) { bx0 = x0; bx1 = x1; by0 = y0; by1 = y1; pstart = a; plen = last - a + 1; }
+          a = last + 1; ++s;
+        }
+      }
+      // Two pieces whose boxes lie farther apart than eps (eps with the margin of the run boxes) have no pair of neighbours.
+      // A pair of pieces the boxes cannot separate (two sides of one obstacle make an L, and an L's box is large) is decided
+      // by the distance test itself, the longer piece's readings in the lanes, the shorter one's coming one by one: no pair
+      // within eps -- separate after all; some pair within eps -- the two pieces are one cluster, PROVIDED each is long enough
+      // to be all core points on its own (a short piece next to a cluster would be border points: the general route's job).
+      // Pieces that are one cluster share a label, the smallest piece number among them (lane s: label of piece s).
+      const double epsx = eps * (1.0 + 1e-6) + 1e-9;
+      const double ax0 = bx0 - epsx, ax1 = bx1 + epsx, ay0 = by0 - epsx, ay1 = by1 + epsx;
+      const bool joined = wrap_close && nseg >= 2;     // the last piece and the first: joined across ray 0 by (last, first)
+      int lab = lane;
+      auto relabel = [&](int p, int q2) {
+        const int lp = __builtin_amdgcn_readlane(lab, p), lq = __builtin_amdgcn_readlane(lab, q2);
+        const int lo = min(lp, lq), hi = max(lp, lq);
+        lab = (lab == hi) ? lo : lab;
+      };
+      for (int t = 1; t < nseg && ok; ++t) {
+        const double ox0 = lane_value(bx0, t), ox1 = lane_value(bx1, t), oy0 = lane_value(by0, t), oy1 = lane_value(by1, t);
+        unsigned long long nmk = __ballot((lane < t) & (ox0 <= ax1) & (ox1 >= ax0) & (oy0 <= ay1) & (oy1 >= ay0));
+        if (joined && t == nseg - 1) nmk &= ~1ull;                                  // (joined below)
+        while (nmk && ok) {
+          const int sp = __ffsll((long long)nmk) - 1;
+          nmk &= nmk - 1;
+          const int as = __builtin_amdgcn_readlane(pstart, sp), al = __builtin_amdgcn_readlane(plen, sp);
+          const int bs = __builtin_amdgcn_readlane(pstart, t), bl = __builtin_amdgcn_readlane(plen, t);
+          const bool a_longer = al > bl;
+          const int vs = a_longer ? as : bs, vl = a_longer ? al : bl;               // in the lanes
+          const int ls = a_longer ? bs : as, ll = a_longer ? bl : al;               // one by one
+          bool hit = false;
+#pragma unroll
+          for (int w2 = 0; w2 < WORDS; ++w2) {
+            if (w2 >= NW || w2 * 64 > vs + vl - 1 || w2 * 64 + 63 < vs) continue;
+            const int i2 = w2 * 64 + lane;
+            const bool in = (i2 >= vs) & (i2 < vs + vl);
+            const double mx = pint_[2 * (in ? i2 : vs)], my = pint_[2 * (in ? i2 : vs) + 1];
+            for (int j = ls; j < ls + ll; ++j) {
+              const double dx = mx - pint_[2 * j], dy = my - pint_[2 * j + 1];
+              hit |= in & (dx * dx + dy * dy <= eps2);
+            }
+          }
+          if (__any(hit)) {
+            if (al < min_samples || bl < min_samples) ok = false;
+            else relabel(sp, t);
+          }
+        }
+      }
+      if (joined) relabel(0, nseg - 1);
+      int mlen = 0;                                    // lane L: readings of the cluster labelled L
+      for (int t = 0; t < nseg; ++t) {
+        const int lt = __builtin_amdgcn_readlane(lab, t), nt = __builtin_amdgcn_readlane(plen, t);
+        if (lane == lt) mlen += nt;
+      }
+      // every reading: its piece, the piece's cluster, and the core-point proof
+      bool unproved = false;
+      int rootv[WORDS];
+      int before = 0;                                  // pieces that end before this word
+#pragma unroll
+      for (int w = 0; w < WORDS; ++w) {
+        rootv[w] = -1;
+        if (w >= NW) continue;
+        const int i = w * 64 + lane;
+        const bool valid = i < n_pts;
+        const int pc = min(before + __popcll(brk[w] & ((1ull << lane) - 1ull)), nseg - 1);
+        before += __popcll(brk[w]);
+        const int st = __shfl(pstart, pc, 64), en = st + __shfl(plen, pc, 64) - 1;
+        const int lb = __shfl(lab, pc, 64);
+        const int root = __shfl(pstart, lb, 64), len = __shfl(mlen, lb, 64);
+        const bool dense = len >= min_samples;
+        int cnt = (i > st) + (i < en) + far2[w] + back2[w];
+        if (wrap_close && (i == 0 || i == n_pts - 1)) ++cnt;
+        unproved |= valid & dense & (cnt < min_samples - 1);
+        rootv[w] = valid ? (dense ? root : NO_ROOT) : -1;
+      }
+      if (__any(unproved)) ok = false;
+      if (ok) {
+#pragma unroll
+        for (int w = 0; w < WORDS; ++w) comp_[w * 64 + lane] = rootv[w];
+        chains = true;
+      }
+    }
+  }
+  if (chains) __syncthreads();
+  if (!chains) {
   // row[k][w]: neighbour bits of point lane + 64 k against the 64 points of word w — kept in registers (the lane
   // that owns a point is the only one that reads its row).
   // All-pairs is 147 k distance tests for 384 readings (it was the longest phase of the scan), so the sweep is pruned
@@ -501,7 +669,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
   };
   flatten();
-  int touch[WORDS];                                  // smallest tree root point lane + 64 k touches (NO_ROOT: none)
   for (int round = 0; round < RMAX; ++round) {
     int cw[WORDS];
     unsigned long long rootmask[WORDS];
@@ -541,6 +708,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     if (!__any(changed)) break;
     flatten();
   }
+  }      // (!chains)
   LIDAR_PHASE_END(4);
   // cluster root of every reading (of this lane's point of every word: nobody else asks for it): own component for cores,
   // smallest neighbouring core component for the rest
@@ -787,6 +955,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     g += ng;
   }
   if (lane == 0) { n_inferred[b] = n_out; overflow[b] = ovf; }
+#ifdef LIPMPC_LIDAR_PHASES
+  if (dbg_stop == 9 && lane == 0) {      // wave timing (tools/lidar_wave_times.py): start and end on the 100 MHz wall clock, by robot
+    n_inferred[b] = (int)(t_enter & 0x7fffffff);
+    overflow[b] = (int)(wall_clock64() & 0x7fffffff);
+  }
+#endif
 }
 
 // Weight of every robot for the launch order of its scan: an ESTIMATE of its reading count -- every ray, if the robot stands
@@ -884,7 +1058,7 @@ __global__ __launch_bounds__(1024) void lidar_order_kernel(long B, int period, i
     const long pos = ((q + 1) * period <= B && (q & 1)) ? q * period + (period - 1 - s2) : r;
     order[pos] = (int32_t)i;
   }
-  if (threadIdx.x == 0) sched[SCHED_VALID] = (int32_t)B;
+  if (threadIdx.x == 0) { sched[SCHED_VALID] = (int32_t)B; sched[SCHED_PERIOD] = period; }
 }
 
 }  // namespace
