@@ -956,6 +956,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   }
   if (lane == 0) { n_inferred[b] = n_out; overflow[b] = ovf; }
 #ifdef LIPMPC_LIDAR_PHASES
+  if (dbg_stop == 10 && lane == 0) n_inferred[b] = chains ? 1 : 0;      // which route clustered this scan (tools/lidar_wave_times.py)
   if (dbg_stop == 9 && lane == 0) {      // wave timing (tools/lidar_wave_times.py): start and end on the 100 MHz wall clock, by robot
     n_inferred[b] = (int)(t_enter & 0x7fffffff);
     overflow[b] = (int)(wall_clock64() & 0x7fffffff);

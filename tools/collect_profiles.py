@@ -53,7 +53,7 @@ for wl, rename in (("cfg4", None), ("rollout", None), ("cfg5_scan", "cfg5_scan_B
                 v["trace_us_slowest_kernel"] = max(spans)
             else:
                 v["trace_us_per_launch"] = max(spans)
-            slots = min(v.get("sq_waves", 0) or 1024, 1024 * (2 if wl == "cfg5_scan" else 1))
+            slots = min(v.get("sq_waves", 0) or 1024, 1024 * (4 if wl == "cfg5_scan" else 1))     # the scan runs four waves per SIMD
             span_us = (v.get("workload", {}).get("ms", 0) * 1e3) if wl == "cfg4" else max(spans)
             if v.get("sq_wave_cycles") and span_us:
                 v["wave_alive_fraction"] = v["sq_wave_cycles"] * 4 / (span_us * 1e-6 * CLOCK_GHZ * 1e9 * slots)

@@ -1,4 +1,4 @@
-"""Dev tool: when every scan of the config-5 bench batch starts and ends (-DLIPMPC_LIDAR_PHASES variant, LIPMPC_LIDAR_STOP=9:
+"""Dev tool (LIPMPC_LIDAR_STOP=10: which share of the scans the chain proof clusters, by reading count).  LIPMPC_LIDAR_STOP=9: when every scan of the config-5 bench batch starts and ends (-DLIPMPC_LIDAR_PHASES variant, LIPMPC_LIDAR_STOP=9:
 each wave records the 100 MHz wall clock at entry and exit), against its reading count: is the launch bound by its heaviest
 waves' own length or by what shares their SIMD?"""
 import sys, os, numpy as np, torch
@@ -6,7 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import lipmpc
 from importlib import import_module
 synth = import_module("humanoid-navigation-using-mpc-ldcbf_amd.synth")
-assert os.environ.get("LIPMPC_LIDAR_STOP") == "9"
+mode = os.environ.get("LIPMPC_LIDAR_STOP")
+assert mode in ("9", "10")
 dev = torch.device("cuda", 0); B = 4096
 exy, env = synth.synthetic_fields(1, 20, -1.0, 6.0, (-5.0, -5.0), (50.0, 50.0), seed=9, delta=0.6)
 rings = [exy[0, j, : env[0, j]] for j in range(20) if env[0, j] > 0]
@@ -21,6 +22,14 @@ sen = sensor.alloc_outputs(B, rings=False, c_eta=True)
 sched = sensor.make_schedule(B)
 for rep in range(3):
     sensor.sense(state, noise, out=sen, schedule=sched); torch.cuda.synchronize()
+if mode == "10":
+    route = sen["n_inferred"].cpu().numpy()
+    print("clustered by chains: %.1f %% of the %d scans" % (100.0 * route.mean(), B))
+    for lo, hi in ((0, 80), (80, 112), (112, 144), (144, 192), (192, 256), (256, 361)):
+        m = (npts >= lo) & (npts < hi)
+        if m.any():
+            print("  readings %3d-%3d: %4d scans, %.1f %% by chains" % (lo, hi - 1, m.sum(), 100.0 * route[m].mean()))
+    sys.exit(0)
 t0 = sen["n_inferred"].cpu().numpy().astype(np.int64); t1 = sen["overflow"].cpu().numpy().astype(np.int64)
 base = t0.min()
 start, end = (t0 - base) / 100.0, (t1 - base) / 100.0            # us
