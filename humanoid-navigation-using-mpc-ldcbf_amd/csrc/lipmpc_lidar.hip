@@ -450,6 +450,65 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       const double epsx = eps * (1.0 + 1e-6) + 1e-9;
       const double ax0 = bx0 - epsx, ax1 = bx1 + epsx, ay0 = by0 - epsx, ay1 = by1 + epsx;
       const bool joined = wrap_close && nseg >= 2;     // the last piece and the first: joined across ray 0 by (last, first)
+      auto wave_min = [&](int v) {
+        v = min(v, lipmpc_dev::row_xor<1>(v)); v = min(v, lipmpc_dev::row_xor<2>(v)); v = min(v, lipmpc_dev::row_xor<4>(v));
+        v = min(v, lipmpc_dev::row_xor<8>(v)); v = min(v, wave_xor16(v)); v = min(v, wave_xor32(v));
+        return __builtin_amdgcn_readfirstlane(v);
+      };
+      // every reading's piece; the readings of long-enough pieces that the cheap count does NOT prove to be core points (the
+      // ends of a piece whose second neighbour is farther than eps, mostly) get their neighbours counted exactly, one wave-wide
+      // sweep each: core after all, or not -- then the reading is a border point of whatever cluster its core neighbours
+      // belong to (assigned further down), it links no pieces, and it cannot be a cluster's first core point.
+      int pcv[WORDS], stv[WORDS], env[WORDS];
+      bool noncore[WORDS];
+      unsigned long long susm[WORDS], ncm[WORDS];
+      int before = 0, nsus = 0;
+      const int len_first = __builtin_amdgcn_readlane(plen, 0), len_last = __builtin_amdgcn_readlane(plen, max(nseg - 1, 0));
+#pragma unroll
+      for (int w = 0; w < WORDS; ++w) {
+        pcv[w] = 0; stv[w] = 0; env[w] = 0; noncore[w] = false; susm[w] = 0ull; ncm[w] = 0ull;
+        if (w >= NW) continue;
+        const int i = w * 64 + lane;
+        const bool valid = i < n_pts;
+        pcv[w] = min(before + __popcll(brk[w] & ((1ull << lane) - 1ull)), nseg - 1);
+        before += __popcll(brk[w]);
+        stv[w] = __shfl(pstart, pcv[w], 64);
+        const int pl = __shfl(plen, pcv[w], 64);
+        env[w] = stv[w] + pl - 1;
+        const int lenj = pl + ((joined && pcv[w] == 0) ? len_last : 0) + ((joined && pcv[w] == nseg - 1) ? len_first : 0);
+        int cnt = (i > stv[w]) + (i < env[w]) + far2[w] + back2[w];
+        if (wrap_close && (i == 0 || i == n_pts - 1)) ++cnt;
+        susm[w] = __ballot(valid & (lenj >= min_samples) & (cnt < min_samples - 1));
+        nsus += __popcll(susm[w]);
+      }
+      if (nsus > 8) ok = false;
+      if (ok && nsus > 0) {
+#pragma unroll
+        for (int we = 0; we < WORDS; ++we) {
+          unsigned long long m = susm[we];
+          while (m) {
+            const int le = __ffsll((long long)m) - 1, e = we * 64 + le;
+            m &= m - 1;
+            const double ex = pint_[2 * e], ey = pint_[2 * e + 1];
+            int c = 0;
+#pragma unroll
+            for (int w = 0; w < WORDS; ++w) {
+              if (w >= NW) continue;
+              const int i = w * 64 + lane;
+              const double dx = pint_[2 * min(i, n_pts - 1)] - ex, dy = pint_[2 * min(i, n_pts - 1) + 1] - ey;
+              c += __popcll(__ballot((i < n_pts) & (dx * dx + dy * dy <= eps2)));
+            }
+            if (c < min_samples) {
+              // only the free END of a piece may fail to be a core point: anywhere else the chain of core points would be cut
+              const int se = __builtin_amdgcn_readlane(stv[we], le), ee = __builtin_amdgcn_readlane(env[we], le);
+              if ((e != se && e != ee) || (joined && (e == 0 || e == n_pts - 1))) ok = false;
+              if (lane == le) noncore[we] = true;
+            }
+          }
+        }
+#pragma unroll
+        for (int w = 0; w < WORDS; ++w) ncm[w] = __ballot(noncore[w]);
+      }
       int lab = lane;
       auto relabel = [&](int p, int q2) {
         const int lp = __builtin_amdgcn_readlane(lab, p), lq = __builtin_amdgcn_readlane(lab, q2);
@@ -468,19 +527,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           const bool a_longer = al > bl;
           const int vs = a_longer ? as : bs, vl = a_longer ? al : bl;               // in the lanes
           const int ls = a_longer ? bs : as, ll = a_longer ? bl : al;               // one by one
-          bool hit = false;
+          // (a pair within eps has each reading inside the other piece's box grown by eps: of two walls meeting in a corner
+          // only the readings near the corner take part)
+          const int vi = a_longer ? sp : t, li = a_longer ? t : sp;
+          const double vx0 = lane_value(bx0, vi) - epsx, vx1 = lane_value(bx1, vi) + epsx, vy0 = lane_value(by0, vi) - epsx, vy1 = lane_value(by1, vi) + epsx;
+          const double lx0 = lane_value(bx0, li) - epsx, lx1 = lane_value(bx1, li) + epsx, ly0 = lane_value(by0, li) - epsx, ly1 = lane_value(by1, li) + epsx;
+          // One pair within eps settles it, and where there is one it sits near the cut between the two pieces more often
+          // than not: the one-by-one side is walked from its end nearer the other piece, and the walk stops at the first pair.
+          const bool upwards = li > vi;
+          bool hit = false, found = false;
 #pragma unroll
-          for (int w2 = 0; w2 < WORDS; ++w2) {
-            if (w2 >= NW || w2 * 64 > vs + vl - 1 || w2 * 64 + 63 < vs) continue;
-            const int i2 = w2 * 64 + lane;
-            const bool in = (i2 >= vs) & (i2 < vs + vl);
-            const double mx = pint_[2 * (in ? i2 : vs)], my = pint_[2 * (in ? i2 : vs) + 1];
-            for (int j = ls; j < ls + ll; ++j) {
-              const double dx = mx - pint_[2 * j], dy = my - pint_[2 * j + 1];
-              hit |= in & (dx * dx + dy * dy <= eps2);
+          for (int wq = 0; wq < WORDS; ++wq) {
+            const int wl = upwards ? wq : WORDS - 1 - wq;
+            if (found || wl >= NW || wl * 64 > ls + ll - 1 || wl * 64 + 63 < ls) continue;
+            const int il = wl * 64 + lane;
+            const bool inl = (il >= ls) & (il < ls + ll) & !noncore[wl];
+            const double qx = pint_[2 * (inl ? il : ls)], qy = pint_[2 * (inl ? il : ls) + 1];
+            const unsigned long long cm = __ballot(inl & (qx >= vx0) & (qx <= vx1) & (qy >= vy0) & (qy <= vy1));
+            if (!cm) continue;
+#pragma unroll
+            for (int w2 = 0; w2 < WORDS; ++w2) {
+              if (w2 >= NW || w2 * 64 > vs + vl - 1 || w2 * 64 + 63 < vs) continue;
+              const int i2 = w2 * 64 + lane;
+              const bool inv = (i2 >= vs) & (i2 < vs + vl) & !noncore[w2];
+              const double mx = pint_[2 * (inv ? i2 : vs)], my = pint_[2 * (inv ? i2 : vs) + 1];
+              const bool in = inv & (mx >= lx0) & (mx <= lx1) & (my >= ly0) & (my <= ly1);
+              if (found || !__any(in)) continue;
+              unsigned long long c2 = cm;
+              while (c2 && !found) {
+#pragma unroll
+                for (int rep4 = 0; rep4 < 4; ++rep4) {
+                  if (!c2) break;
+                  const int bit = upwards ? __ffsll((long long)c2) - 1 : 63 - __clzll((long long)c2);
+                  c2 &= ~(1ull << bit);
+                  const int j = wl * 64 + bit;
+                  const double dx = mx - pint_[2 * j], dy = my - pint_[2 * j + 1];
+                  hit |= in & (dx * dx + dy * dy <= eps2);
+                }
+                found = __any(hit);
+              }
             }
           }
-          if (__any(hit)) {
+          if (found) {
             if (al < min_samples || bl < min_samples) ok = false;
             else relabel(sp, t);
           }
@@ -492,28 +580,58 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const int lt = __builtin_amdgcn_readlane(lab, t), nt = __builtin_amdgcn_readlane(plen, t);
         if (lane == lt) mlen += nt;
       }
-      // every reading: its piece, the piece's cluster, and the core-point proof
-      bool unproved = false;
+      // every reading: its cluster's label, whether it is a core point; a cluster's root = its first core point
+      int lbv[WORDS];
+      bool corev[WORDS];
+#pragma unroll
+      for (int w = 0; w < WORDS; ++w) {
+        lbv[w] = 0; corev[w] = false;
+        if (w >= NW) continue;
+        lbv[w] = __shfl(lab, pcv[w], 64);
+        corev[w] = (w * 64 + lane < n_pts) & (__shfl(mlen, lbv[w], 64) >= min_samples) & !noncore[w];
+      }
+      int croot = NO_ROOT;                             // lane L: first core point of the cluster labelled L
+      for (int t = 0; t < nseg && ok; ++t) {
+        if (__builtin_amdgcn_readlane(lab, t) != t) continue;                       // (t is its cluster's label)
+        if (__builtin_amdgcn_readlane(mlen, t) < min_samples) continue;             // (noise)
+        int first = NO_ROOT;
+#pragma unroll
+        for (int w = 0; w < WORDS; ++w) if (w < NW && corev[w] && lbv[w] == t) first = min(first, w * 64 + lane);
+        first = wave_min(first);
+        if (first == NO_ROOT) ok = false;                                           // (a long piece without a core point)
+        if (lane == t) croot = first;
+      }
       int rootv[WORDS];
-      int before = 0;                                  // pieces that end before this word
 #pragma unroll
       for (int w = 0; w < WORDS; ++w) {
         rootv[w] = -1;
         if (w >= NW) continue;
-        const int i = w * 64 + lane;
-        const bool valid = i < n_pts;
-        const int pc = min(before + __popcll(brk[w] & ((1ull << lane) - 1ull)), nseg - 1);
-        before += __popcll(brk[w]);
-        const int st = __shfl(pstart, pc, 64), en = st + __shfl(plen, pc, 64) - 1;
-        const int lb = __shfl(lab, pc, 64);
-        const int root = __shfl(pstart, lb, 64), len = __shfl(mlen, lb, 64);
-        const bool dense = len >= min_samples;
-        int cnt = (i > st) + (i < en) + far2[w] + back2[w];
-        if (wrap_close && (i == 0 || i == n_pts - 1)) ++cnt;
-        unproved |= valid & dense & (cnt < min_samples - 1);
-        rootv[w] = valid ? (dense ? root : NO_ROOT) : -1;
+        const int root = __shfl(croot, lbv[w], 64);
+        rootv[w] = (w * 64 + lane < n_pts) ? (corev[w] ? root : NO_ROOT) : -1;
       }
-      if (__any(unproved)) ok = false;
+      // the readings found not to be core points: border points of the cluster with the smallest root among their core
+      // neighbours (noise if they have none)
+      if (ok && nsus > 0) {
+#pragma unroll
+        for (int we = 0; we < WORDS; ++we) {
+          unsigned long long m = ncm[we];
+          while (m) {
+            const int le = __ffsll((long long)m) - 1, e = we * 64 + le;
+            m &= m - 1;
+            const double ex = pint_[2 * e], ey = pint_[2 * e + 1];
+            int best = NO_ROOT;
+#pragma unroll
+            for (int w = 0; w < WORDS; ++w) {
+              if (w >= NW) continue;
+              const int i = w * 64 + lane;
+              const double dx = pint_[2 * min(i, n_pts - 1)] - ex, dy = pint_[2 * min(i, n_pts - 1) + 1] - ey;
+              if (corev[w] && dx * dx + dy * dy <= eps2) best = min(best, rootv[w]);
+            }
+            best = wave_min(best);
+            if (lane == le) touch[we] = best;
+          }
+        }
+      }
       if (ok) {
 #pragma unroll
         for (int w = 0; w < WORDS; ++w) comp_[w * 64 + lane] = rootv[w];

@@ -41,6 +41,14 @@ for lo, hi in ((0, 80), (80, 112), (112, 144), (144, 192), (192, 256), (256, 361
         print("readings %3d-%3d: %4d waves, duration mean %.1f max %.1f us, end mean %.1f max %.1f us" % (lo, hi - 1, m.sum(), dur[m].mean(), dur[m].max(), end[m].mean(), end[m].max()))
 late = np.argsort(-end)[:12]
 print("latest waves (readings, start, duration, end):", [(int(npts[i]), round(start[i], 1), round(dur[i], 1), round(end[i], 1)) for i in late])
+hits = o["hits"].cpu().numpy()
+for i in late[:3]:                                   # what the slowest scans look like: pieces of consecutive readings within eps
+    v = ~np.isnan(hits[i, :, 0]); pts = hits[i][v]
+    d = np.hypot(*(pts[1:] - pts[:-1]).T)
+    cuts = np.nonzero(d > 0.3)[0]
+    sizes = np.diff(np.concatenate([[0], cuts + 1, [len(pts)]]))
+    print("  scan with %d readings ending at %.1f us: pieces %s, extent %.2f x %.2f m, robot at (%.2f, %.2f)" % (
+        len(pts), end[i], sizes.tolist(), np.ptp(pts[:, 0]), np.ptp(pts[:, 1]), pos[i, 0].item(), pos[i, 1].item()))
 order = sched[2:2 + B].cpu().numpy()
 posn = np.empty(B, np.int64); posn[order] = np.arange(B)
 simd = posn % 1024
