@@ -375,13 +375,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   for (int w = 0; w < WORDS; ++w) touch[w] = NO_ROOT;
   // ---- 2a. the readings as chains ---------------------------------------------------------------------
   // Readings come in ray order: consecutive ones on one obstacle's outline lie centimetres apart, eps is 0.3 m.  Cut the list
-  // where two consecutive readings are farther apart than eps: if the pieces' bounding boxes are farther than eps from one
-  // another (the first and the last piece may instead be joined across ray 0 by the pair (last, first) itself), no reading has
-  // a neighbour outside its piece; if moreover every reading of a piece of at least min_samples readings provably has
-  // min_samples - 1 neighbours among the readings one and two places from it, every reading of such a piece is a core point
-  // and the piece, being chained, is ONE cluster -- while a shorter piece holds no core point and is noise.  That is DBSCAN's
-  // answer (clusters numbered by their first reading, no border points) from three distance tests per reading instead of the
-  // neighbour rows; whenever any part of the proof fails the scan takes the general route below.
+  // where two consecutive readings are farther apart than eps.  A reading of a piece of at least min_samples readings is a core
+  // point if it has min_samples - 1 neighbours among the readings one and two places from it; where that cheap count falls short
+  // the neighbours are counted exactly (only a piece's free end may turn out not to be a core point: it is then a border point).
+  // Pieces whose bounding boxes are farther apart than eps hold no neighbours of each other; pieces the boxes cannot separate are
+  // decided by the distance test between their core points (one pair within eps: one cluster); the last piece and the first may
+  // be joined across ray 0 by the pair (last, first).  A chained piece of core points is ONE cluster, numbered by its first core
+  // point; a piece shorter than min_samples holds no core point and is noise; a border point goes to the cluster with the smallest
+  // root among its core neighbours.  That is DBSCAN's answer without the neighbour rows; whenever any part of the proof fails
+  // (more than 8 pieces, a non-core reading inside a piece, a short piece within eps of another, ...) the scan takes the general
+  // route below.
   bool chains = false;
   if (n_pts >= 1) {
 #pragma clang fp contract(off)
