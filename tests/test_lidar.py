@@ -618,11 +618,15 @@ def test_gpu_lidar_fuzz_against_oracle(lidar_range, resolution, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("eps,min_samples", [(0.3, 3), (0.3, 2), (0.3, 4), (0.3, 5), (0.3, 1), (0.3, 7), (0.12, 3), (0.6, 3), (0.04, 3), (0.02, 2)])
-def test_gpu_clustering_routes_against_oracle(monkeypatch, eps, min_samples):
+@pytest.mark.parametrize("eps,min_samples,field", [(0.3, 3, "crowded"), (0.3, 2, "crowded"), (0.3, 4, "crowded"), (0.3, 5, "crowded"),
+                                                   (0.3, 1, "crowded"), (0.3, 7, "crowded"), (0.12, 3, "crowded"), (0.6, 3, "crowded"),
+                                                   (0.04, 3, "crowded"), (0.02, 2, "crowded"), (0.3, 3, "pickets"), (0.12, 3, "pickets"),
+                                                   (0.3, 5, "pickets")])
+def test_gpu_clustering_routes_against_oracle(monkeypatch, eps, min_samples, field):
     """The scan clusters by chains of consecutive readings where it can prove that this is DBSCAN's answer, and by neighbour
-    rows where it cannot (csrc/lipmpc_lidar.hip, 2a): 512 robots anywhere on a crowded map (inside obstacles too), over eps /
-    min_samples that make the proof succeed for nearly all of them, for some, and for none -- the labels of every reading equal
+    rows where it cannot (csrc/lipmpc_lidar_chains.inc / _rows.inc): 512 robots anywhere on a crowded map (inside obstacles too)
+    or in a field of 90 pickets, over eps / min_samples that make the proof succeed for nearly all of them, for some, and for
+    none -- the labels of every reading equal
     oracle/lidar_oracle.py::dbscan_labels on the scan's own readings, and the rings are the oracle's hulls of those clusters."""
     torch = pytest.importorskip("torch")
     import lipmpc
@@ -631,10 +635,17 @@ def test_gpu_clustering_routes_against_oracle(monkeypatch, eps, min_samples):
     lidar_mod = import_module("humanoid-navigation-using-mpc-ldcbf_amd.lidar")
     monkeypatch.setattr(lidar_mod, "DBSCAN_EPS", eps)
     monkeypatch.setattr(lidar_mod, "DBSCAN_MIN_SAMPLES", min_samples)
-    exy, env = synth.synthetic_fields(1, 20, -1.0, 6.0, (-5.0, -5.0), (50.0, 50.0), seed=9, delta=0.6)
-    rings = [exy[0, j, : env[0, j]] for j in range(20) if env[0, j] > 0]
-    B = 512
     rng = np.random.default_rng(int(eps * 1000) + min_samples)
+    if field == "crowded":
+        exy, env = synth.synthetic_fields(1, 20, -1.0, 6.0, (-5.0, -5.0), (50.0, 50.0), seed=9, delta=0.6)
+        rings = [exy[0, j, : env[0, j]] for j in range(20) if env[0, j] > 0]
+    else:
+        # a field of pickets: 90 squares of 0.12 m, 0.35-0.9 m apart -- scans of many short pieces (more than the chain route's
+        # eight, pieces shorter than min_samples next to longer ones, gaps around eps): the general route and its hand-over
+        cs = rng.uniform(-1.0, 6.0, (90, 2))
+        sq = 0.06 * np.array([[-1.0, -1.0], [1.0, -1.0], [1.0, 1.0], [-1.0, 1.0]])
+        rings = [c + sq for c in cs]
+    B = 512
     pos = rng.uniform(-1.0, 6.0, (B, 2))
     st = np.zeros((B, 5)); st[:, 0] = pos[:, 0]; st[:, 2] = pos[:, 1]
     noise = 0.01 * rng.standard_normal((B, 360, 2))
@@ -659,4 +670,4 @@ def test_gpu_clustering_routes_against_oracle(monkeypatch, eps, min_samples):
         for j, ring in enumerate(want):
             assert _same_ring(g["obs_xy"][b, j, : g["obs_nv"][b, j]], ring), (b, j)
             n_rings += 1
-    assert n_clusters > 0 and (n_rings > B // 4 or eps < 0.1)
+    assert n_clusters > 0 and (n_rings > B // 4 or eps < 0.1 or field == "pickets")
