@@ -621,7 +621,7 @@ def test_gpu_lidar_fuzz_against_oracle(lidar_range, resolution, seed):
 @pytest.mark.parametrize("eps,min_samples,field", [(0.3, 3, "crowded"), (0.3, 2, "crowded"), (0.3, 4, "crowded"), (0.3, 5, "crowded"),
                                                    (0.3, 1, "crowded"), (0.3, 7, "crowded"), (0.12, 3, "crowded"), (0.6, 3, "crowded"),
                                                    (0.04, 3, "crowded"), (0.02, 2, "crowded"), (0.3, 3, "pickets"), (0.12, 3, "pickets"),
-                                                   (0.3, 5, "pickets")])
+                                                   (0.3, 5, "pickets"), (0.3, 3, "far"), (0.3, 4, "far")])
 def test_gpu_clustering_routes_against_oracle(monkeypatch, eps, min_samples, field):
     """The scan clusters by chains of consecutive readings where it can prove that this is DBSCAN's answer, and by neighbour
     rows where it cannot (csrc/lipmpc_lidar_chains.inc / _rows.inc): 512 robots anywhere on a crowded map (inside obstacles too)
@@ -636,7 +636,8 @@ def test_gpu_clustering_routes_against_oracle(monkeypatch, eps, min_samples, fie
     monkeypatch.setattr(lidar_mod, "DBSCAN_EPS", eps)
     monkeypatch.setattr(lidar_mod, "DBSCAN_MIN_SAMPLES", min_samples)
     rng = np.random.default_rng(int(eps * 1000) + min_samples)
-    if field == "crowded":
+    lidar_range, resolution = (3.0, 180) if field == "far" else (1.5, 360)      # "far": sparse readings on far walls, gaps near eps
+    if field != "pickets":
         exy, env = synth.synthetic_fields(1, 20, -1.0, 6.0, (-5.0, -5.0), (50.0, 50.0), seed=9, delta=0.6)
         rings = [exy[0, j, : env[0, j]] for j in range(20) if env[0, j] > 0]
     else:
@@ -648,8 +649,8 @@ def test_gpu_clustering_routes_against_oracle(monkeypatch, eps, min_samples, fie
     B = 512
     pos = rng.uniform(-1.0, 6.0, (B, 2))
     st = np.zeros((B, 5)); st[:, 0] = pos[:, 0]; st[:, 2] = pos[:, 1]
-    noise = 0.01 * rng.standard_normal((B, 360, 2))
-    sensor = lipmpc.LidarSensor(rings, lidar_range=1.5, resolution=360, n_obs_max=24, v_max=64)
+    noise = 0.01 * rng.standard_normal((B, resolution, 2))
+    sensor = lipmpc.LidarSensor(rings, lidar_range=lidar_range, resolution=resolution, n_obs_max=24, v_max=64)
     out = sensor.sense(torch.as_tensor(st, device="cuda"), torch.as_tensor(noise, device="cuda"), with_debug=True, c_eta=True)
     torch.cuda.synchronize()
     g = {k: v.cpu().numpy() for k, v in out.items()}
