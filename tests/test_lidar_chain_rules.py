@@ -146,13 +146,30 @@ def _short_piece_beside_a_sparse_end(rng, eps):
     return P + rng.normal(0, 0.003, P.shape)
 
 
+def _two_sparse_ends(rng, eps):
+    """Two long pieces whose sparse ends (readings that may not be core points) come within eps of each other: a pair of
+    neighbours, but only a pair of CORE points makes the two pieces one cluster."""
+    def piece(m):
+        steps = np.full(m, 0.04)
+        steps[-int(rng.integers(1, 3)):] = eps * rng.uniform(0.55, 0.98)
+        xs = np.concatenate([[0.0], np.cumsum(steps)])
+        return np.stack([xs, np.zeros_like(xs)], 1)
+    A, B = piece(int(rng.integers(3, 25))), piece(int(rng.integers(3, 25)))
+    ang = rng.uniform(0, 2 * np.pi)
+    rot = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+    B = (B - B[-1]) @ rot.T + A[-1] + rng.uniform(-1, 1, 2) * eps * rng.uniform(0.2, 1.3)
+    P = [np.vstack([A, B[::-1]]), np.vstack([A[::-1], B]), np.vstack([B, A]), np.vstack([A, B])][int(rng.integers(0, 4))]
+    return P + rng.normal(0, 0.003, P.shape)
+
+
 @pytest.mark.parametrize("ms", [1, 2, 3, 4, 5])
 def test_chain_rules_never_contradict_dbscan(ms):
     rng = np.random.default_rng(100 + ms)
     eps = 0.3
     claimed = declined = 0
     for _ in range(4000):
-        P = _sequence(rng, eps) if rng.uniform() < 0.75 else _short_piece_beside_a_sparse_end(rng, eps)
+        u = rng.uniform()
+        P = _sequence(rng, eps) if u < 0.6 else (_short_piece_beside_a_sparse_end(rng, eps) if u < 0.8 else _two_sparse_ends(rng, eps))
         got = chain_labels(P, eps, ms)
         if got is None:
             declined += 1
