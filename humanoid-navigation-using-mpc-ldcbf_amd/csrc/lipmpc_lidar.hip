@@ -334,17 +334,23 @@ __global__ __launch_bounds__(1024) void lidar_order_kernel(long B, int period, i
   __syncthreads();
   for (long i = threadIdx.x; i < B; i += blockDim.x) atomicAdd(&cursor_[RMAX - min(max(w[i], 0), RMAX)], 1);
   __syncthreads();
-  // exclusive prefix sum of the bin counts (Hillis-Steele over the first NBIN threads; a serial loop of one thread was most of
-  // this kernel's time)
+  // exclusive prefix sum of the bin counts: each of the first NBIN / 64 waves scans its 64 bins in registers, the waves' totals
+  // go through LDS once (two barriers; a serial loop of one thread, then a Hillis-Steele scan with a barrier pair per step,
+  // were most of this kernel's time)
   const int t = threadIdx.x;
-  int mine = t < NBIN ? cursor_[t] : 0, acc = mine;
-  for (int d = 1; d < NBIN; d <<= 1) {
-    if (t < NBIN) scan_[t] = acc;
+  {
+    const int mine = t < NBIN ? cursor_[t] : 0;
+    int acc = mine;                                   // inclusive scan inside the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(acc, d, 64); if ((t & 63) >= d) acc += o; }
+    if (t < NBIN && (t & 63) == 63) scan_[t >> 6] = acc;
     __syncthreads();
-    if (t < NBIN && t >= d) acc += scan_[t - d];
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < NBIN / 64; ++k) if (k < (t >> 6)) base += scan_[k];
     __syncthreads();
+    if (t < NBIN) cursor_[t] = base + acc - mine;
   }
-  if (t < NBIN) cursor_[t] = acc - mine;
   __syncthreads();
   // Rank -> launch position.  While every wave of the grid is resident at once, launch positions `period` apart share a SIMD
   // (period = 4 x compute units: the dispatcher deals single-wave blocks round-robin, tools/lidar_placement.py), so the ranks go
